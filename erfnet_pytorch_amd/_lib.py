@@ -1,0 +1,117 @@
+"""ctypes binding of ``liberfnet_hip.so`` (C ABI declared in ``include/erfnet_hip.h``).
+
+The library is the only compute path for tensors that live on a GPU: when it cannot be loaded
+every GPU call raises, there is no fallback.  ``build()`` compiles it in-tree with hipcc for gfx950
+(cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liberfnet_hip.so")
+_SRC = os.path.join(_HERE, "csrc")
+_lock = threading.Lock()
+_lib = None
+_load_error = None
+
+vp = C.c_void_p
+ll = C.c_longlong
+
+
+class BnStruct(C.Structure):
+    """Mirror of ``erf_bn_t``."""
+    _fields_ = [("mode", C.c_int), ("gamma", vp), ("beta", vp), ("running_mean", vp),
+                ("running_var", vp), ("save_mean", vp), ("save_invstd", vp),
+                ("momentum", C.c_float), ("eps", C.c_float)]
+
+
+def sources():
+    return [os.path.join(_SRC, f) for f in sorted(os.listdir(_SRC))] + \
+        [os.path.join(os.path.dirname(_HERE), "include", "erfnet_hip.h")]
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/erfnet_hip.hip -> liberfnet_hip.so for gfx950 if it is missing or stale."""
+    srcs = sources()
+    if not force and os.path.exists(_SO) and \
+            os.path.getmtime(_SO) >= max(os.path.getmtime(s) for s in srcs):
+        return _SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", _SO, os.path.join(_SRC, "erfnet_hip.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_PROTOS = {
+    "erf_version": (C.c_int, []),
+    "erf_last_error": (C.c_char_p, []),
+    "erf_launch_count": (C.c_ulonglong, []),
+    "erf_workspace_bytes": (C.c_size_t, [ll, C.c_int]),
+    "erf_downsampler_forward": (C.c_int, [vp, ll, ll, ll, ll, vp, vp, C.POINTER(BnStruct), vp, vp,
+                                          C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                          C.c_size_t, vp]),
+    "erf_downsampler_backward": (C.c_int, [vp, ll, ll, ll, ll, vp, C.POINTER(BnStruct), vp, vp, vp,
+                                           vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, vp, C.c_size_t, vp]),
+    "erf_nb1d_forward": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(BnStruct),
+                                   C.POINTER(BnStruct), vp, C.c_int, vp, C.POINTER(vp), C.c_int,
+                                   C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "erf_nb1d_backward": (C.c_int, [vp, C.POINTER(vp), C.POINTER(BnStruct), C.POINTER(BnStruct), vp,
+                                    C.c_int, vp, C.POINTER(vp), vp, vp, C.POINTER(vp),
+                                    C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,
+                                    C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "erf_upsampler_forward": (C.c_int, [vp, vp, vp, C.POINTER(BnStruct), vp, vp, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "erf_upsampler_backward": (C.c_int, [vp, vp, C.POINTER(BnStruct), vp, vp, vp, vp, vp, vp, vp, vp,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                         C.c_size_t, vp]),
+    "erf_outconv_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, vp]),
+    "erf_outconv_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, vp, C.c_size_t, vp]),
+    "erf_conv2d_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, vp]),
+    "erf_conv2d_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+
+def lib():
+    """The loaded library; raises RuntimeError (never falls back) when it is unavailable."""
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_SO):
+            _load_error = (f"{_SO} is missing: build it with `python -c 'import __graft_entry__ "
+                           f"as g; g.build()'` (hipcc --offload-arch=gfx950)")
+            raise RuntimeError(_load_error)
+        try:
+            handle = C.CDLL(_SO)
+            for name, (res, args) in _PROTOS.items():
+                fn = getattr(handle, name)
+                fn.restype = res
+                fn.argtypes = args
+        except (OSError, AttributeError) as e:
+            _load_error = f"cannot load {_SO}: {e}"
+            raise RuntimeError(_load_error) from e
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("erfnet_hip: " + lib().erf_last_error().decode("utf-8", "replace"))
+
+
+def launch_count():
+    return int(lib().erf_launch_count())

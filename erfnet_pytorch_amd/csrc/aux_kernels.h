@@ -1,0 +1,600 @@
+// Memory-bound companions of the implicit-GEMM kernels: the 3-channel network-input downsampler,
+// 2x2 max-pool (forward / backward), BatchNorm statistics / apply / backward, element-wise
+// gradient masking and the 2x2 stride-2 output transposed convolution.  All NHWC fp32.
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// DownsamplerBlock on the network input (Cin = 3): direct 3x3 stride-2 convolution + 2x2 max-pool,
+// one thread per output pixel.  x is read through its strides (NCHW images need no repacking).
+// Weights [Cc][3][3][3] and bias are staged in LDS (broadcast reads).  Output NHWC [*, Cc+3].
+struct FirstDownDesc {
+    const float *x;
+    long long sn, sc, sh, sw;
+    const float *w;      // [Cc][27]
+    float *out;          // [N][Ho][Wo][Cc+3]
+    Epilogue epi;
+    int N, H, W, Cc;
+};
+
+#define FD_MAX_CC 61
+__global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc d)
+{
+    __shared__ float ws[FD_MAX_CC * 28];
+    const int Cout = d.Cc + 3;
+    for (int i = threadIdx.x; i < d.Cc * 28; i += 256) {
+        const int co = i / 28, e = i % 28;
+        ws[i] = e < 27 ? d.w[co * 27 + e] : 0.0f;
+    }
+    __syncthreads();
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const long long M = (long long)d.N * Ho * Wo;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int n = (int)(m / (Ho * Wo));
+    const int rem = (int)(m - (long long)n * Ho * Wo);
+    const int oh = rem / Wo, ow = rem - oh * Wo;
+    float xin[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+                float v = 0.0f;
+                if (ih >= 0 && iw >= 0 && ih < d.H && iw < d.W)
+                    v = d.x[n * d.sn + ci * d.sc + ih * d.sh + iw * d.sw];
+                xin[ci * 9 + kh * 3 + kw] = v;
+            }
+    float *o = d.out + m * Cout;
+    for (int co = 0; co < d.Cc; ++co) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 27; ++e) acc = fmaf(xin[e], ws[co * 28 + e], acc);
+        float sc, sh;
+        epi_channel_affine(d.epi, co, sc, sh);
+        o[co] = epi_finish(d.epi, acc * sc + sh, m, n, co, Cout);
+    }
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+        // window (2oh..2oh+1, 2ow..2ow+1) = taps kh,kw in {1,2}
+        const float a = xin[ci * 9 + 4], b = xin[ci * 9 + 5], c = xin[ci * 9 + 7], e = xin[ci * 9 + 8];
+        float mx = a;
+        if (b > mx) mx = b;
+        if (c > mx) mx = c;
+        if (e > mx) mx = e;
+        const int co = d.Cc + ci;
+        Epilogue ep = d.epi;
+        ep.bias = nullptr;
+        float sc, sh;
+        epi_channel_affine(ep, co, sc, sh);
+        o[co] = epi_finish(d.epi, mx * sc + sh, m, n, co, Cout);
+    }
+}
+
+// Weight/bias gradient of the above: thread (co, e) of a block accumulates
+// sum_pix g[pix][co] * patch[pix][e] over the block's pixel slab, from LDS tiles.
+struct FirstDownWgradDesc {
+    const float *x;
+    long long sn, sc, sh, sw;
+    const float *g;      // [M][g_C] gradient wrt the pre-activation concat, conv channels first
+    float *partial;      // [nsplit][Cc*27 + Cc]
+    int N, H, W, Cc, g_C;
+    int split_pixels;
+};
+
+__global__ __launch_bounds__(512) void first_down_wgrad_kernel(const FirstDownWgradDesc d)
+{
+    constexpr int PT = 64;     // pixels per LDS tile
+    __shared__ float patch[PT * 28];
+    __shared__ float gt[PT * 16];   // Cc <= 16 per pass
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const long long M = (long long)d.N * Ho * Wo;
+    const long long mbeg = (long long)blockIdx.x * d.split_pixels;
+    long long mend = mbeg + d.split_pixels;
+    if (mend > M) mend = M;
+    const int tid = threadIdx.x;
+    const int co = tid / 28, e = tid % 28;   // 16 x 28 = 448 active threads
+    const bool active = co < d.Cc && co < 16;
+    float acc = 0.0f;
+    for (long long mb = mbeg; mb < mend; mb += PT) {
+        for (int i = tid; i < PT * 28; i += 512) {
+            const int p = i / 28, q = i % 28;
+            const long long m = mb + p;
+            float v = 0.0f;
+            if (m < mend) {
+                if (q == 27) v = 1.0f;     // bias column
+                else {
+                    const int n = (int)(m / (Ho * Wo));
+                    const int rem = (int)(m - (long long)n * Ho * Wo);
+                    const int oh = rem / Wo, ow = rem - oh * Wo;
+                    const int ci = q / 9, kh = (q % 9) / 3, kw = q % 3;
+                    const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+                    if (ih >= 0 && iw >= 0 && ih < d.H && iw < d.W)
+                        v = d.x[n * d.sn + ci * d.sc + ih * d.sh + iw * d.sw];
+                }
+            }
+            patch[i] = v;
+        }
+        for (int i = tid; i < PT * 16; i += 512) {
+            const int p = i / 16, c = i % 16;
+            const long long m = mb + p;
+            gt[i] = (m < mend && c < d.Cc) ? d.g[m * d.g_C + c] : 0.0f;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 8
+            for (int p = 0; p < PT; ++p) acc = fmaf(gt[p * 16 + co], patch[p * 28 + e], acc);
+        }
+        __syncthreads();
+    }
+    if (active) {
+        float *P = d.partial + (long long)blockIdx.x * (d.Cc * 27 + d.Cc);
+        if (e < 27) P[co * 27 + e] = acc;
+        else P[d.Cc * 27 + co] = acc;
+    }
+}
+
+// out[i] = sum_s partial[s][i]
+__global__ __launch_bounds__(256) void reduce_flat_kernel(const float *partial, float *dw, float *db,
+                                                          int nsplit, int nw, int nb)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nw + nb) return;
+    float s = 0.0f;
+    for (int i = 0; i < nsplit; ++i) s += partial[(long long)i * (nw + nb) + idx];
+    if (idx < nw) dw[idx] = s;
+    else if (db) db[idx - nw] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 stride-2 max-pool of in[N][H][W][C] into channels [out_coff, out_coff+C) of
+// out[N][H/2][W/2][out_C], with the shared epilogue.  One thread per (output pixel, 4 channels).
+struct PoolDesc {
+    const float *in;
+    float *out;
+    Epilogue epi;
+    int N, H, W, C, out_C, out_coff;
+};
+
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolDesc d)
+{
+    const int Ho = d.H / 2, Wo = d.W / 2, C4 = d.C / 4;
+    const long long total = (long long)d.N * Ho * Wo * C4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C4) * 4;
+    const long long m = idx / C4;
+    const int n = (int)(m / (Ho * Wo));
+    const int rem = (int)(m - (long long)n * Ho * Wo);
+    const int oh = rem / Wo, ow = rem - oh * Wo;
+    const float *p = d.in + (((long long)n * d.H + 2 * oh) * d.W + 2 * ow) * d.C + c;
+    const f32x4 v00 = *reinterpret_cast<const f32x4 *>(p);
+    const f32x4 v01 = *reinterpret_cast<const f32x4 *>(p + d.C);
+    const f32x4 v10 = *reinterpret_cast<const f32x4 *>(p + (long long)d.W * d.C);
+    const f32x4 v11 = *reinterpret_cast<const f32x4 *>(p + (long long)d.W * d.C + d.C);
+    f32x4 o;
+    Epilogue ep = d.epi;
+    ep.bias = nullptr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float mx = v00[e];
+        if (v01[e] > mx) mx = v01[e];
+        if (v10[e] > mx) mx = v10[e];
+        if (v11[e] > mx) mx = v11[e];
+        const int co = d.out_coff + c + e;
+        float sc, sh;
+        epi_channel_affine(ep, co, sc, sh);
+        o[e] = epi_finish(d.epi, mx * sc + sh, m, n, co, d.out_C);
+    }
+    *reinterpret_cast<f32x4 *>(d.out + m * d.out_C + d.out_coff + c) = o;
+}
+
+// Max-pool backward: dx[n][2oh+a][2ow+b][c] = (first maximum of the window in scan order) ?
+// g[n][oh][ow][g_coff+c] : 0.  Writes every element of dx.
+struct PoolBwdDesc {
+    const float *in, *g;
+    float *dx;
+    int N, H, W, C, g_C, g_coff;
+};
+
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdDesc d)
+{
+    const int Ho = d.H / 2, Wo = d.W / 2;
+    const long long total = (long long)d.N * Ho * Wo * d.C;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % d.C);
+    const long long m = idx / d.C;
+    const int n = (int)(m / (Ho * Wo));
+    const int rem = (int)(m - (long long)n * Ho * Wo);
+    const int oh = rem / Wo, ow = rem - oh * Wo;
+    const long long base = (((long long)n * d.H + 2 * oh) * d.W + 2 * ow) * d.C + c;
+    const long long o01 = d.C, o10 = (long long)d.W * d.C, o11 = o10 + d.C;
+    const float v00 = d.in[base], v01 = d.in[base + o01], v10 = d.in[base + o10], v11 = d.in[base + o11];
+    int best = 0;
+    float mx = v00;
+    if (v01 > mx) { mx = v01; best = 1; }
+    if (v10 > mx) { mx = v10; best = 2; }
+    if (v11 > mx) { mx = v11; best = 3; }
+    const float gv = d.g[m * d.g_C + d.g_coff + c];
+    d.dx[base] = best == 0 ? gv : 0.0f;
+    d.dx[base + o01] = best == 1 ? gv : 0.0f;
+    d.dx[base + o10] = best == 2 ? gv : 0.0f;
+    d.dx[base + o11] = best == 3 ? gv : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm.  Statistics are accumulated per thread in fp32 over a short run of pixels, combined in
+// LDS and added to global double accumulators (sums[0..C) = sum x, sums[C..2C) = sum x^2 or the
+// second moment named below).
+// bn_stats_kernel: x [M][C].   bn_bwd_stats_kernel: sum g and sum g*xhat with g = gy*(mask>0)*nscale.
+struct BnStatsDesc {
+    const float *x;        // pre-BN tensor [M][C]
+    const float *gy;       // backward only
+    const float *mask;     // backward only, may be NULL: gy counted where mask > 0
+    const float *nscale;   // backward only, may be NULL: [N][C]
+    const float *mean, *invstd;
+    double *sums;          // [2C], zeroed by the caller
+    long long M;
+    int C, pix_per_image, rows_per_block;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const BnStatsDesc d)
+{
+    __shared__ float red[2][256];
+    const int C = d.C;
+    const int tpr = 256 / C > 0 ? 256 / C : 1;       // threads sharing a channel (C <= 256)
+    const int c = threadIdx.x % C, rr = threadIdx.x / C;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (rr < tpr) {
+        const long long r0 = (long long)blockIdx.x * d.rows_per_block;
+        long long r1 = r0 + d.rows_per_block;
+        if (r1 > d.M) r1 = d.M;
+        const float mean = BWD ? d.mean[c] : 0.0f, inv = BWD ? d.invstd[c] : 0.0f;
+        for (long long r = r0 + rr; r < r1; r += tpr) {
+            const float xv = d.x[r * C + c];
+            if (BWD) {
+                float g = d.gy[r * C + c];
+                if (d.mask && !(d.mask[r * C + c] > 0.0f)) g = 0.0f;
+                if (d.nscale) g *= d.nscale[(r / d.pix_per_image) * C + c];
+                s0 += g;
+                s1 += g * (xv - mean) * inv;
+            } else {
+                s0 += xv;
+                s1 += xv * xv;
+            }
+        }
+    }
+    red[0][threadIdx.x] = s0;
+    red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < tpr; ++k) { a += red[0][threadIdx.x + k * C]; b += red[1][threadIdx.x + k * C]; }
+        atomicAdd(&d.sums[threadIdx.x], a);
+        atomicAdd(&d.sums[C + threadIdx.x], b);
+    }
+}
+
+// mean / invstd from the sums; running statistics updated as nn.BatchNorm2d does in training
+// (momentum, unbiased variance).
+__global__ void bn_finalize_kernel(const double *sums, float *save_mean, float *save_invstd,
+                                   float *run_mean, float *run_var, long long M, int C, float momentum,
+                                   float eps)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mean = sums[c] / (double)M;
+    double var = sums[C + c] / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) run_mean[c] = (float)((1.0 - momentum) * run_mean[c] + momentum * mean);
+    if (run_var) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
+    }
+}
+
+// Eval mode needs mean/invstd in the same form for backward.
+__global__ void bn_eval_prepare_kernel(const float *run_mean, const float *run_var, float *save_mean,
+                                       float *save_invstd, int C, float eps)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    save_mean[c] = run_mean[c];
+    save_invstd[c] = 1.0f / sqrtf(run_var[c] + eps);
+}
+
+// Element-wise pass over [M][C] (float4): out = epilogue(in).  Used for BatchNorm apply (+dropout
+// scale, residual, ReLU) and for gradient masking.
+struct EltDesc {
+    const float *in;
+    float *out;
+    Epilogue epi;
+    long long M;
+    int C, pix_per_image;
+};
+
+__global__ __launch_bounds__(256) void elt_kernel(const EltDesc d)
+{
+    const int C4 = d.C / 4;
+    const long long total = d.M * C4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C4) * 4;
+        const long long m = idx / C4;
+        const int n = (int)(m / d.pix_per_image);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(d.in + m * d.C + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sc, sh;
+            epi_channel_affine(d.epi, c + e, sc, sh);
+            o[e] = epi_finish(d.epi, v[e] * sc + sh, m, n, c + e, d.C);
+        }
+        *reinterpret_cast<f32x4 *>(d.out + m * d.C + c) = o;
+    }
+}
+
+// BatchNorm backward apply: with g = gy*(mask>0)*nscale,
+//   train: dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M);  eval: dx = gamma*invstd*g.
+// dgamma = sum_gx, dbeta = sum_g are written by block 0.
+struct BnBwdDesc {
+    const float *x, *gy, *mask, *nscale, *gamma, *mean, *invstd;
+    const double *sums;
+    float *dx, *dgamma, *dbeta;
+    long long M;
+    int C, pix_per_image, training;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdDesc d)
+{
+    const int C4 = d.C / 4;
+    const long long total = d.M * C4;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < d.C; c += 256) {
+            if (d.dbeta) d.dbeta[c] = (float)d.sums[c];
+            if (d.dgamma) d.dgamma[c] = (float)d.sums[d.C + c];
+        }
+    const double invM = 1.0 / (double)d.M;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % C4) * 4;
+        const long long m = idx / C4;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(d.x + m * d.C + c);
+        f32x4 g = *reinterpret_cast<const f32x4 *>(d.gy + m * d.C + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = c + e;
+            float gv = g[e];
+            if (d.mask && !(d.mask[m * d.C + ch] > 0.0f)) gv = 0.0f;
+            if (d.nscale) gv *= d.nscale[(m / d.pix_per_image) * d.C + ch];
+            const float gi = (d.gamma ? d.gamma[ch] : 1.0f) * d.invstd[ch];
+            if (d.training) {
+                const float xh = (xv[e] - d.mean[ch]) * d.invstd[ch];
+                const float mg = (float)(d.sums[ch] * invM), mgx = (float)(d.sums[d.C + ch] * invM);
+                o[e] = gi * (gv - mg - xh * mgx);
+            } else {
+                o[e] = gi * gv;
+            }
+        }
+        *reinterpret_cast<f32x4 *>(d.dx + m * d.C + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output ConvTranspose2d(CIN, ncls, 2, stride=2): out[n][o][2i+a][2j+b] = bias[o] + sum_c x[c]*w[c][o][a][b].
+// One thread per input pixel; x (NHWC) in registers, weights in LDS as [o][a][b][c]; the thread
+// writes float2 {b=0,1} per (o,a) into the NCHW output — consecutive lanes are consecutive j, so a
+// wave writes 512 contiguous bytes per store.  SOFTMAX fuses softmax over o (ncls <= 32).
+#define OC_CIN 16
+#define OC_MAX_NCLS 32
+struct OutConvDesc {
+    const float *x, *w, *b;
+    float *y;
+    int N, H, W, ncls;
+};
+
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
+{
+    __shared__ __attribute__((aligned(16))) float ws[OC_MAX_NCLS * 4 * OC_CIN];
+    __shared__ float bs[OC_MAX_NCLS];
+    for (int i = threadIdx.x; i < d.ncls * 4 * OC_CIN; i += 256) {
+        const int c = i % OC_CIN, ab = (i / OC_CIN) % 4, o = i / (OC_CIN * 4);
+        ws[i] = d.w[(c * d.ncls + o) * 4 + ab];
+    }
+    for (int i = threadIdx.x; i < d.ncls; i += 256) bs[i] = d.b ? d.b[i] : 0.0f;
+    __syncthreads();
+    const long long M = (long long)d.N * d.H * d.W;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int n = (int)(m / (d.H * d.W));
+    const int rem = (int)(m - (long long)n * d.H * d.W);
+    const int i = rem / d.W, j = rem - i * d.W;
+    float xv[OC_CIN];
+#pragma unroll
+    for (int q = 0; q < OC_CIN / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(d.x + m * OC_CIN + q * 4);
+        xv[q * 4] = v[0]; xv[q * 4 + 1] = v[1]; xv[q * 4 + 2] = v[2]; xv[q * 4 + 3] = v[3];
+    }
+    const int Ho = 2 * d.H, Wo = 2 * d.W;
+    if (!SOFTMAX) {
+        for (int o = 0; o < d.ncls; ++o) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float r0 = bs[o], r1 = bs[o];
+                const float *w0 = &ws[((o * 2 + a) * 2 + 0) * OC_CIN];
+                const float *w1 = &ws[((o * 2 + a) * 2 + 1) * OC_CIN];
+#pragma unroll
+                for (int c = 0; c < OC_CIN; ++c) { r0 = fmaf(xv[c], w0[c], r0); r1 = fmaf(xv[c], w1[c], r1); }
+                f32x2 st = {r0, r1};
+                *reinterpret_cast<f32x2 *>(d.y + (((long long)n * d.ncls + o) * Ho + 2 * i + a) * Wo + 2 * j) = st;
+            }
+        }
+    } else {
+        // two passes over the classes per output position: max / sum of exp, then normalise
+        float mx[4], sum[4];
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) { mx[ab] = -INFINITY; sum[ab] = 0.0f; }
+        for (int o = 0; o < d.ncls; ++o)
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                float r = bs[o];
+                const float *w0 = &ws[(o * 4 + ab) * OC_CIN];
+#pragma unroll
+                for (int c = 0; c < OC_CIN; ++c) r = fmaf(xv[c], w0[c], r);
+                mx[ab] = fmaxf(mx[ab], r);
+            }
+        for (int o = 0; o < d.ncls; ++o)
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                float r = bs[o];
+                const float *w0 = &ws[(o * 4 + ab) * OC_CIN];
+#pragma unroll
+                for (int c = 0; c < OC_CIN; ++c) r = fmaf(xv[c], w0[c], r);
+                sum[ab] += expf(r - mx[ab]);
+            }
+        for (int o = 0; o < d.ncls; ++o)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float r[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float v = bs[o];
+                    const float *w0 = &ws[((o * 2 + a) * 2 + b) * OC_CIN];
+#pragma unroll
+                    for (int c = 0; c < OC_CIN; ++c) v = fmaf(xv[c], w0[c], v);
+                    r[b] = expf(v - mx[a * 2 + b]) / sum[a * 2 + b];
+                }
+                f32x2 st = {r[0], r[1]};
+                *reinterpret_cast<f32x2 *>(d.y + (((long long)n * d.ncls + o) * Ho + 2 * i + a) * Wo + 2 * j) = st;
+            }
+    }
+}
+
+// dx[n][i][j][c] = sum_{o,a,b} gy[n][o][2i+a][2j+b] * w[c][o][a][b]   (gy NCHW, dx NHWC)
+struct OutConvBwdDesc {
+    const float *x, *w, *gy;
+    float *dx, *partial;
+    int N, H, W, ncls, split_pixels;
+};
+
+__global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc d)
+{
+    __shared__ __attribute__((aligned(16))) float ws[OC_MAX_NCLS * 4 * OC_CIN];
+    for (int i = threadIdx.x; i < d.ncls * 4 * OC_CIN; i += 256) {
+        const int c = i % OC_CIN, ab = (i / OC_CIN) % 4, o = i / (OC_CIN * 4);
+        ws[i] = d.w[(c * d.ncls + o) * 4 + ab];
+    }
+    __syncthreads();
+    const long long M = (long long)d.N * d.H * d.W;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int n = (int)(m / (d.H * d.W));
+    const int rem = (int)(m - (long long)n * d.H * d.W);
+    const int i = rem / d.W, j = rem - i * d.W;
+    const int Ho = 2 * d.H, Wo = 2 * d.W;
+    float acc[OC_CIN];
+#pragma unroll
+    for (int c = 0; c < OC_CIN; ++c) acc[c] = 0.0f;
+    for (int o = 0; o < d.ncls; ++o)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const f32x2 g = *reinterpret_cast<const f32x2 *>(
+                d.gy + (((long long)n * d.ncls + o) * Ho + 2 * i + a) * Wo + 2 * j);
+            const float *w0 = &ws[((o * 2 + a) * 2 + 0) * OC_CIN];
+            const float *w1 = &ws[((o * 2 + a) * 2 + 1) * OC_CIN];
+#pragma unroll
+            for (int c = 0; c < OC_CIN; ++c) acc[c] = fmaf(g[0], w0[c], fmaf(g[1], w1[c], acc[c]));
+        }
+#pragma unroll
+    for (int q = 0; q < OC_CIN / 4; ++q) {
+        f32x4 v = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+        *reinterpret_cast<f32x4 *>(d.dx + m * OC_CIN + q * 4) = v;
+    }
+}
+
+// dw[c][o][a][b] = sum_pix x[pix][c]*gy[o][pix,a,b]; db[o] = sum gy.  Thread (oab, cq) accumulates
+// 4 input channels for one (o,a,b) over the block's pixel slab from LDS tiles; a 5th "channel
+// group" row carries the bias sum.  Slab layout: [ncls*4][16] then [ncls*4] bias partials.
+__global__ __launch_bounds__(512) void outconv_wgrad_kernel(const OutConvBwdDesc d)
+{
+    constexpr int PT = 64;                                  // pixels (along j) per tile
+    __shared__ __attribute__((aligned(16))) float xt[PT * OC_CIN];
+    __shared__ float gt[OC_MAX_NCLS * 4 * (PT + 1)];
+    const int tid = threadIdx.x;
+    const int nab = d.ncls * 4;
+    const int oab = tid % 128, cq = tid / 128;              // cq in 0..3 -> channels 4cq..4cq+3
+    const bool active = oab < nab;
+    const long long M = (long long)d.N * d.H * d.W;
+    const long long mbeg = (long long)blockIdx.x * d.split_pixels;
+    long long mend = mbeg + d.split_pixels;
+    if (mend > M) mend = M;
+    const int Ho = 2 * d.H, Wo = 2 * d.W;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    float bacc = 0.0f;
+    for (long long mb = mbeg; mb < mend; mb += PT) {
+        for (int i = tid; i < PT * OC_CIN / 4; i += 512) {
+            const int p = i / (OC_CIN / 4);
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (mb + p < mend) v = *reinterpret_cast<const f32x4 *>(d.x + (mb + p) * OC_CIN + (i % (OC_CIN / 4)) * 4);
+            *reinterpret_cast<f32x4 *>(&xt[i * 4]) = v;
+        }
+        for (int i = tid; i < nab * PT; i += 512) {
+            const int p = i % PT, q = i / PT;           // q = (o*2 + a)*2 + b
+            const int b = q & 1, a = (q >> 1) & 1, o = q >> 2;
+            const long long m = mb + p;
+            float v = 0.0f;
+            if (m < mend) {
+                const int n = (int)(m / (d.H * d.W));
+                const int rem = (int)(m - (long long)n * d.H * d.W);
+                const int ii = rem / d.W, jj = rem - ii * d.W;
+                v = d.gy[(((long long)n * d.ncls + o) * Ho + 2 * ii + a) * Wo + 2 * jj + b];
+            }
+            gt[q * (PT + 1) + p] = v;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 8
+            for (int p = 0; p < PT; ++p) {
+                const float g = gt[oab * (PT + 1) + p];
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xt[p * OC_CIN + cq * 4]);
+                acc[0] = fmaf(g, xv[0], acc[0]); acc[1] = fmaf(g, xv[1], acc[1]);
+                acc[2] = fmaf(g, xv[2], acc[2]); acc[3] = fmaf(g, xv[3], acc[3]);
+                bacc += g;
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        float *P = d.partial + (long long)blockIdx.x * (nab * OC_CIN + nab);
+        *reinterpret_cast<f32x4 *>(&P[oab * OC_CIN + cq * 4]) = acc;
+        if (cq == 0) P[nab * OC_CIN + oab] = bacc;
+    }
+}
+
+// dw[c][o][a][b] = sum_s P[s][oab][c];  db[o] = sum_s sum_ab P[s][bias][o*4+ab]
+__global__ __launch_bounds__(256) void outconv_wreduce_kernel(const float *partial, float *dw, float *db,
+                                                              int nsplit, int ncls)
+{
+    const int nab = ncls * 4, slab = nab * OC_CIN + nab;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < nab * OC_CIN) {
+        float s = 0.0f;
+        for (int i = 0; i < nsplit; ++i) s += partial[(long long)i * slab + idx];
+        const int c = idx % OC_CIN, oab = idx / OC_CIN;
+        dw[c * nab + oab] = s;
+    } else if (idx < nab * OC_CIN + ncls && db) {
+        const int o = idx - nab * OC_CIN;
+        float s = 0.0f;
+        for (int i = 0; i < nsplit; ++i)
+            for (int ab = 0; ab < 4; ++ab) s += partial[(long long)i * slab + nab * OC_CIN + o * 4 + ab];
+        db[o] = s;
+    }
+}

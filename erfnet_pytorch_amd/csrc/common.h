@@ -1,0 +1,106 @@
+// Shared descriptors and helpers of the ERFNet HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define ERF_MAX_TAPS 9
+#define ERF_MAX_GROUPS 4
+
+// Per-channel affine applied in a kernel epilogue: BatchNorm in eval mode, or in train mode
+// once the batch statistics are known.  v = (v - mean) * invstd * gamma + beta, where
+// invstd = var_is_invstd ? var[c] : rsqrt(var[c] + eps).
+struct BnAffine {
+    const float *gamma, *beta, *mean, *var;
+    float eps;
+    int var_is_invstd;
+    int on;
+};
+
+// Epilogue shared by the convolution, pooling and element-wise kernels, applied in this order:
+//   v += bias[c]; v = bn(v); v *= nscale[n][c]; v += res[pix][c]; v = relu(v); v = mask[pix][c] > 0 ? v : 0
+// res and mask are NHWC tensors addressed with the output's pixel index.
+struct Epilogue {
+    const float *bias;
+    BnAffine bn;
+    const float *nscale;   // [N][Nout]  (Dropout2d keep/scale factors)
+    const float *res;
+    int res_C, res_coff;
+    const float *mask;
+    int mask_C, mask_coff;
+    int relu;
+};
+
+// Implicit-GEMM convolution: out[pix(m)][co] = epi( sum_t sum_k in[src(m,t)][k] * W[t][k][co] ).
+//   m = (n, gi, gj) enumerates an output grid GH x GW per image;
+//   source pixel  = (gi*ss + tdh[t], gj*ss + tdw[t]) of in[N][in_H][in_W][in_C] (+in_coff), zero outside;
+//   output pixel  = (gi*os + goa[g], gj*os + gob[g]) of out[N][out_H][out_W][out_C] (+out_coff);
+//   weights       : W[t][k][j] = w[woff[t] + k*wsk + j*wsn]  (torch layouts addressed in place);
+//   tap groups    : blockIdx.z = g selects taps [gtap0[g], gtap0[g]+gntaps[g]) — the output-parity
+//                   classes of a stride-2 transposed convolution; ordinary convolutions have 1 group.
+struct IgemmDesc {
+    const float *in, *w;
+    float *out;
+    Epilogue epi;
+    int N, GH, GW;
+    int in_H, in_W, in_C, in_coff, K;
+    int ss;
+    int tdh[ERF_MAX_TAPS], tdw[ERF_MAX_TAPS], woff[ERF_MAX_TAPS];
+    int wsk, wsn;
+    int ngroups, gtap0[ERF_MAX_GROUPS], gntaps[ERF_MAX_GROUPS], goa[ERF_MAX_GROUPS], gob[ERF_MAX_GROUPS];
+    int out_H, out_W, out_C, out_coff, Nout, os;
+    int vec_ok;        // in_C, in_coff, K all multiples of 4 and `in` 16-byte aligned
+    int lane_along_j;  // weight gather: consecutive lanes walk j (wsn < wsk) or k
+};
+
+// Weight gradient: dW[t][k][j] = sum_m in[src(m,t)][k] * g[gpix(m,t)][j], reduced over pixels in
+// `nsplit` slabs: partial[s][t][k][j] (k < K, j < Nout), plus bias row partial_b[s][j].
+//   g pixel = (gi*os + toa[t], gj*os + tob[t]) of g[N][g_H][g_W][g_C] (+g_coff).
+struct WgradDesc {
+    const float *in, *g;
+    float *partial;     // [nsplit][ntaps*K*Nout + Nout]
+    int N, GH, GW;
+    int in_H, in_W, in_C, in_coff, K;
+    int ss, ntaps;
+    int tdh[ERF_MAX_TAPS], tdw[ERF_MAX_TAPS], toa[ERF_MAX_TAPS], tob[ERF_MAX_TAPS];
+    int g_H, g_W, g_C, g_coff, Nout, os;
+    int nsplit, split_pixels;   // pixels per slab (multiple of 32)
+    int itiles, jtiles;
+    int vec_ok;
+};
+
+__device__ __forceinline__ float apply_bn(const BnAffine &bn, float v, int c)
+{
+    const float inv = bn.var_is_invstd ? bn.var[c] : rsqrtf(bn.var[c] + bn.eps);
+    const float g = bn.gamma ? bn.gamma[c] : 1.0f;
+    const float b = bn.beta ? bn.beta[c] : 0.0f;
+    return (v - bn.mean[c]) * (inv * g) + b;
+}
+
+// Channel-only part of the epilogue folded into two numbers: v*sc + sh.
+__device__ __forceinline__ void epi_channel_affine(const Epilogue &e, int c, float &sc, float &sh)
+{
+    sc = 1.0f;
+    sh = e.bias ? e.bias[c] : 0.0f;
+    if (e.bn.on) {
+        const float inv = e.bn.var_is_invstd ? e.bn.var[c] : rsqrtf(e.bn.var[c] + e.bn.eps);
+        const float g = (e.bn.gamma ? e.bn.gamma[c] : 1.0f) * inv;
+        const float b = e.bn.beta ? e.bn.beta[c] : 0.0f;
+        // ((v + bias) - mean) * g + b
+        sh = (sh - e.bn.mean[c]) * g + b;
+        sc = g;
+    }
+}
+
+__device__ __forceinline__ float epi_finish(const Epilogue &e, float v, long long pix, int n, int c,
+                                            int Nout)
+{
+    if (e.nscale) v *= e.nscale[(long long)n * Nout + c];
+    if (e.res) v += e.res[pix * e.res_C + e.res_coff + c];
+    if (e.relu) v = fmaxf(v, 0.0f);
+    if (e.mask) v = e.mask[pix * e.mask_C + e.mask_coff + c] > 0.0f ? v : 0.0f;
+    return v;
+}

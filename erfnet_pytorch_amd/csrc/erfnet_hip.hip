@@ -1,0 +1,815 @@
+// liberfnet_hip.so — C ABI (include/erfnet_hip.h) over the gfx950 kernels in igemm.h / aux_kernels.h.
+// Host side only builds descriptors and launches; it never allocates, copies or synchronises.
+#include "../../include/erfnet_hip.h"
+#include "aux_kernels.h"
+#include "igemm.h"
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::atomic<unsigned long long> g_launches{0};
+
+int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define CHECK_LAUNCH(name)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ != hipSuccess) return fail("%s launch failed: %s", name, hipGetErrorString(e_));    \
+        g_launches.fetch_add(1, std::memory_order_relaxed);                                        \
+    } while (0)
+
+// Bump allocator over the caller's workspace (256-byte granules).
+struct Arena {
+    char *base;
+    size_t size, off;
+    Arena(void *p, size_t n) : base((char *)p), size(n), off(0) {}
+    void *take(size_t bytes)
+    {
+        const size_t a = (off + 255) & ~(size_t)255;
+        if (!base || a + bytes > size) return nullptr;
+        off = a + bytes;
+        return base + a;
+    }
+    float *floats(size_t n) { return (float *)take(n * sizeof(float)); }
+};
+
+const Epilogue kNoEpi = {nullptr, {nullptr, nullptr, nullptr, nullptr, 0.0f, 0, 0}, nullptr,
+                         nullptr, 0, 0, nullptr, 0, 0, 0};
+
+BnAffine bn_eval_affine(const erf_bn_t *bn)
+{
+    BnAffine a = {bn->gamma, bn->beta, bn->running_mean, bn->running_var, bn->eps, 0, 1};
+    return a;
+}
+BnAffine bn_saved_affine(const erf_bn_t *bn)
+{
+    BnAffine a = {bn->gamma, bn->beta, bn->save_mean, bn->save_invstd, bn->eps, 1, 1};
+    return a;
+}
+inline int bn_mode(const erf_bn_t *bn) { return bn ? bn->mode : 0; }
+
+bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// ---------------------------------------------------------------------------------- igemm launch
+int launch_igemm(IgemmDesc &d, hipStream_t st)
+{
+    if (d.K <= 0 || d.Nout <= 0) return fail("igemm: empty contraction");
+    const long long M = (long long)d.N * d.GH * d.GW;
+    if (M == 0) return 0;
+    if (d.in_H >= 32768 || d.in_W >= 32768 || d.GH * d.ss >= 65536 || d.GW * d.ss >= 32768)
+        return fail("igemm: spatial extent too large");
+    if (M * d.os * d.os >= (1LL << 31) || (long long)d.N * d.in_H * d.in_W >= (1LL << 31))
+        return fail("igemm: more than 2^31 pixels");
+    d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && aligned16(d.in)) ? 1 : 0;
+    d.lane_along_j = d.wsn < d.wsk ? 1 : 0;
+    dim3 grid;
+    grid.z = d.ngroups;
+    if (d.Nout > 64) {
+        constexpr int BM = 128, BN = 128;
+        grid.x = (unsigned)((M + BM - 1) / BM);
+        grid.y = (d.Nout + BN - 1) / BN;
+        igemm_f32_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(d);
+    } else if (d.Nout > 32) {
+        constexpr int BM = 256, BN = 64;
+        if (M >= 256LL * BM * 2) {
+            grid.x = (unsigned)((M + BM - 1) / BM);
+            grid.y = (d.Nout + BN - 1) / BN;
+            igemm_f32_kernel<2, 2, 4, 1><<<grid, 256, 0, st>>>(d);
+        } else {
+            grid.x = (unsigned)((M + 127) / 128);
+            grid.y = (d.Nout + BN - 1) / BN;
+            igemm_f32_kernel<1, 2, 4, 1><<<grid, 256, 0, st>>>(d);
+        }
+    } else {
+        constexpr int BN = 32;
+        if (M >= 256LL * 256 * 2) {
+            grid.x = (unsigned)((M + 255) / 256);
+            grid.y = (d.Nout + BN - 1) / BN;
+            igemm_f32_kernel<2, 1, 4, 1><<<grid, 256, 0, st>>>(d);
+        } else {
+            grid.x = (unsigned)((M + 127) / 128);
+            grid.y = (d.Nout + BN - 1) / BN;
+            igemm_f32_kernel<1, 1, 4, 1><<<grid, 256, 0, st>>>(d);
+        }
+    }
+    CHECK_LAUNCH("igemm_f32_kernel");
+    return 0;
+}
+
+// Weight gradient + slab reduction into torch's layout.  `bias_taps`: bit t set = the bias row of
+// tap t enters db (taps whose g pixels partition the gradient tensor).
+int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, int wsn,
+                 unsigned bias_taps, Arena &ar, hipStream_t st)
+{
+    const long long M = (long long)d.N * d.GH * d.GW;
+    if (M >= (1LL << 31)) return fail("wgrad: more than 2^31 pixels");
+    d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && d.g_C % 4 == 0 &&
+                d.g_coff % 4 == 0 && d.Nout % 4 == 0 && aligned16(d.in) && aligned16(d.g)) ? 1 : 0;
+    int IBLK, JBLK, cfg;
+    if (d.K > 64 && d.Nout > 64) { IBLK = 128; JBLK = 128; cfg = 0; }
+    else if (d.K > 64 && d.Nout > 32) { IBLK = 128; JBLK = 64; cfg = 1; }
+    else if (d.K > 32 && d.Nout > 64) { IBLK = 64; JBLK = 128; cfg = 2; }
+    else if (d.K > 32 && d.Nout > 32) { IBLK = 64; JBLK = 64; cfg = 3; }
+    else if (d.K <= 32 && d.Nout > 32) { IBLK = 32; JBLK = 64; cfg = 4; }
+    else if (d.K > 32) { IBLK = 64; JBLK = 32; cfg = 5; }
+    else { IBLK = 32; JBLK = 32; cfg = 6; }
+    d.itiles = (d.K + IBLK - 1) / IBLK;
+    d.jtiles = (d.Nout + JBLK - 1) / JBLK;
+    const int tiles = d.ntaps * d.itiles * d.jtiles;
+    const size_t slab = (size_t)d.ntaps * d.K * d.Nout + (size_t)d.ntaps * d.Nout;
+    long long nsplit = 1536 / tiles;
+    if (nsplit < 1) nsplit = 1;
+    const long long max_by_work = (M + 127) / 128;       // at least 4 MFMA k-tiles per block
+    if (nsplit > max_by_work) nsplit = max_by_work;
+    const long long max_by_mem = (long long)((48u << 20) / (slab * sizeof(float)));
+    if (nsplit > max_by_mem) nsplit = max_by_mem;
+    if (nsplit < 1) nsplit = 1;
+    long long sp = (M + nsplit - 1) / nsplit;
+    sp = (sp + 31) / 32 * 32;
+    nsplit = (M + sp - 1) / sp;
+    d.nsplit = (int)nsplit;
+    d.split_pixels = (int)sp;
+    d.partial = ar.floats(slab * nsplit);
+    if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
+    dim3 grid((unsigned)nsplit, tiles, 1);
+    switch (cfg) {
+    case 0: wgrad_f32_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(d); break;
+    case 1: wgrad_f32_kernel<2, 1, 2, 2><<<grid, 256, 0, st>>>(d); break;
+    case 2: wgrad_f32_kernel<1, 2, 2, 2><<<grid, 256, 0, st>>>(d); break;
+    case 3: wgrad_f32_kernel<1, 1, 2, 2><<<grid, 256, 0, st>>>(d); break;
+    case 4: wgrad_f32_kernel<1, 1, 1, 2><<<grid, 128, 0, st>>>(d); break;
+    case 5: wgrad_f32_kernel<1, 1, 2, 1><<<grid, 128, 0, st>>>(d); break;
+    default: wgrad_f32_kernel<1, 1, 1, 1><<<grid, 64, 0, st>>>(d); break;
+    }
+    CHECK_LAUNCH("wgrad_f32_kernel");
+    ReduceDesc r;
+    r.partial = d.partial; r.dw = dw; r.db = db;
+    r.nsplit = d.nsplit; r.ntaps = d.ntaps; r.K = d.K; r.Nout = d.Nout;
+    for (int t = 0; t < d.ntaps; ++t) r.woff[t] = woff[t];
+    r.wsk = wsk; r.wsn = wsn; r.bias_taps = bias_taps;
+    const long long tot = (long long)d.ntaps * d.K * d.Nout + d.Nout;
+    reduce_partials_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(r);
+    CHECK_LAUNCH("reduce_partials_kernel");
+    return 0;
+}
+
+unsigned grid_for(long long work_items, int per_block = 256, unsigned cap = 8192)
+{
+    long long g = (work_items + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int launch_elt(const float *in, float *out, const Epilogue &epi, long long M, int C, int pix_per_image,
+               hipStream_t st)
+{
+    if (C % 4) return fail("element-wise pass needs C %% 4 == 0 (C = %d)", C);
+    EltDesc e = {in, out, epi, M, C, pix_per_image};
+    elt_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(e);
+    CHECK_LAUNCH("elt_kernel");
+    return 0;
+}
+
+// g_out = gy * (mask > 0)
+int launch_mask(const float *gy, const float *mask, float *out, long long M, int C, hipStream_t st)
+{
+    Epilogue e = kNoEpi;
+    e.mask = mask; e.mask_C = C; e.mask_coff = 0;
+    return launch_elt(gy, out, e, M, C, 1, st);
+}
+
+// Batch statistics of pre [M][C] -> bn->save_mean / save_invstd (+ running stats).
+int bn_train_stats(const erf_bn_t *bn, const float *pre, long long M, int C, Arena &ar, hipStream_t st)
+{
+    if (C > 256) return fail("BatchNorm kernels support C <= 256 (C = %d)", C);
+    if (!bn->save_mean || !bn->save_invstd) return fail("BatchNorm train mode needs save_mean/save_invstd");
+    double *sums = (double *)ar.take(sizeof(double) * 2 * C);
+    if (!sums) return fail("workspace too small for BatchNorm sums");
+    hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
+    const int rows = 2048;
+    BnStatsDesc s = {pre, nullptr, nullptr, nullptr, nullptr, nullptr, sums, M, C, 1, rows};
+    bn_stats_kernel<false><<<(unsigned)((M + rows - 1) / rows), 256, 0, st>>>(s);
+    CHECK_LAUNCH("bn_stats_kernel");
+    bn_finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(sums, bn->save_mean, bn->save_invstd, bn->running_mean,
+                                                    bn->running_var, M, C, bn->momentum, bn->eps);
+    CHECK_LAUNCH("bn_finalize_kernel");
+    return 0;
+}
+
+// BatchNorm backward on g = gy*(mask>0)*nscale: dx (may alias nothing), dgamma, dbeta.
+int bn_backward(const erf_bn_t *bn, const float *pre, const float *gy, const float *mask,
+                const float *nscale, float *dx, float *dgamma, float *dbeta, long long M, int C,
+                int pix_per_image, Arena &ar, hipStream_t st)
+{
+    if (C > 256 || C % 4) return fail("BatchNorm kernels support C <= 256, C %% 4 == 0 (C = %d)", C);
+    if (!pre) return fail("BatchNorm backward needs the saved pre-normalisation tensor");
+    if (!bn->save_mean || !bn->save_invstd) return fail("BatchNorm backward needs save_mean/save_invstd");
+    double *sums = (double *)ar.take(sizeof(double) * 2 * C);
+    if (!sums) return fail("workspace too small for BatchNorm sums");
+    hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
+    const int rows = 2048;
+    BnStatsDesc s = {pre, gy, mask, nscale, bn->save_mean, bn->save_invstd, sums, M, C, pix_per_image, rows};
+    bn_stats_kernel<true><<<(unsigned)((M + rows - 1) / rows), 256, 0, st>>>(s);
+    CHECK_LAUNCH("bn_stats_kernel");
+    BnBwdDesc b = {pre, gy, mask, nscale, bn->gamma, bn->save_mean, bn->save_invstd, sums,
+                   dx, dgamma, dbeta, M, C, pix_per_image, bn->mode == 2};
+    bn_bwd_apply_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(b);
+    CHECK_LAUNCH("bn_bwd_apply_kernel");
+    return 0;
+}
+
+// In eval mode the backward formulas read mean/invstd from save_*; fill them from running stats.
+int bn_eval_prepare(const erf_bn_t *bn, int C, hipStream_t st)
+{
+    if (!bn->save_mean || !bn->save_invstd) return 0;   // inference without backward
+    bn_eval_prepare_kernel<<<(C + 63) / 64, 64, 0, st>>>(bn->running_mean, bn->running_var, bn->save_mean,
+                                                        bn->save_invstd, C, bn->eps);
+    CHECK_LAUNCH("bn_eval_prepare_kernel");
+    return 0;
+}
+
+void zero_desc(IgemmDesc &d)
+{
+    memset(&d, 0, sizeof(d));
+    d.ngroups = 1;
+    d.os = 1;
+    d.ss = 1;
+}
+
+// 1-D convolution of non_bottleneck_1d: along H (axis 0) or W (axis 1), 3 taps, dilation dil.
+// transpose = data gradient (taps mirrored, weight indices swapped).
+void conv1d_desc(IgemmDesc &d, const float *in, const float *w, float *out, int N, int C, int H, int W,
+                 int axis, int dil, bool transpose)
+{
+    zero_desc(d);
+    d.in = in; d.w = w; d.out = out;
+    d.N = N; d.GH = H; d.GW = W;
+    d.in_H = H; d.in_W = W; d.in_C = C; d.in_coff = 0; d.K = C;
+    d.out_H = H; d.out_W = W; d.out_C = C; d.out_coff = 0; d.Nout = C;
+    d.gtap0[0] = 0; d.gntaps[0] = 3;
+    for (int t = 0; t < 3; ++t) {
+        const int off = (transpose ? -(t - 1) : (t - 1)) * dil;
+        d.tdh[t] = axis == 0 ? off : 0;
+        d.tdw[t] = axis == 1 ? off : 0;
+        d.woff[t] = t;
+    }
+    if (!transpose) { d.wsk = 3; d.wsn = C * 3; }       // W[co][ci][t]: k = ci, j = co
+    else { d.wsk = C * 3; d.wsn = 3; }                  // k = co, j = ci
+}
+
+void wgrad1d_desc(WgradDesc &d, const float *in, const float *g, int N, int C, int H, int W, int axis, int dil)
+{
+    memset(&d, 0, sizeof(d));
+    d.in = in; d.g = g;
+    d.N = N; d.GH = H; d.GW = W;
+    d.in_H = H; d.in_W = W; d.in_C = C; d.K = C;
+    d.ss = 1; d.os = 1; d.ntaps = 3;
+    for (int t = 0; t < 3; ++t) {
+        d.tdh[t] = axis == 0 ? (t - 1) * dil : 0;
+        d.tdw[t] = axis == 1 ? (t - 1) * dil : 0;
+    }
+    d.g_H = H; d.g_W = W; d.g_C = C; d.Nout = C;
+}
+
+// Tap tables of a 3x3 stride-2 transposed convolution seen from the output-parity classes
+// (a,b) = (oh&1, ow&1): kh = 1 for a = 0 (source row i), kh in {0 (source i+1), 2 (source i)} for a = 1.
+struct ParityTaps {
+    int ntaps, kh[9], kw[9], dh[9], dw[9], oa[9], ob[9];
+    int gtap0[4], gntaps[4], goa[4], gob[4];
+    unsigned rep_mask;    // one tap per class with zero source offset
+};
+ParityTaps parity_taps()
+{
+    ParityTaps p;
+    memset(&p, 0, sizeof(p));
+    int t = 0;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            const int g = a * 2 + b;
+            p.gtap0[g] = t; p.goa[g] = a; p.gob[g] = b;
+            for (int kh = 0; kh < 3; ++kh) {
+                if ((a == 0) != (kh == 1)) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    if ((b == 0) != (kw == 1)) continue;
+                    p.kh[t] = kh; p.kw[t] = kw;
+                    p.dh[t] = kh == 0 ? 1 : 0; p.dw[t] = kw == 0 ? 1 : 0;
+                    p.oa[t] = a; p.ob[t] = b;
+                    if (p.dh[t] == 0 && p.dw[t] == 0) p.rep_mask |= 1u << t;
+                    ++t;
+                }
+            }
+            p.gntaps[g] = t - p.gtap0[g];
+        }
+    p.ntaps = t;
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int erf_version(void) { return 100; }
+const char *erf_last_error(void) { return g_err; }
+unsigned long long erf_launch_count(void) { return g_launches.load(); }
+
+size_t erf_workspace_bytes(long long n_pixels, int max_c)
+{
+    // three gradient/activation temporaries + weight-gradient slabs + BatchNorm sums + slack
+    return (size_t)n_pixels * (size_t)max_c * sizeof(float) * 3 + (size_t)(56u << 20);
+}
+
+// ================================================================================ Downsampler
+int erf_downsampler_forward(const float *x, long long sn, long long sc, long long sh, long long sw,
+                            const float *w, const float *b, const erf_bn_t *bn, float *y, float *pre,
+                            int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if ((H & 1) || (W & 1)) return fail("DownsamplerBlock: H and W must be even (got %dx%d)", H, W);
+    const int Cc = Cout - Cin, Ho = H / 2, Wo = W / 2;
+    if (Cc <= 0) return fail("DownsamplerBlock: noutput must exceed ninput");
+    const long long Mo = (long long)N * Ho * Wo;
+    const int mode = bn_mode(bn);
+    // BatchNorm in train mode (or in eval mode when backward needs the pre-BN tensor) runs as
+    // conv/pool -> pre, [statistics,] normalise + ReLU -> y; otherwise BN folds into the epilogue.
+    const bool two_pass = mode == 2 || (mode == 1 && pre);
+    float *dst = two_pass ? pre : y;
+    if (two_pass && !pre) {
+        dst = ar.floats((size_t)Mo * Cout);
+        if (!dst) return fail("DownsamplerBlock: workspace too small");
+    }
+    Epilogue epi = kNoEpi;
+    epi.bias = b;
+    if (mode == 1 && !two_pass) epi.bn = bn_eval_affine(bn);
+    epi.relu = !two_pass;
+    if (Cin == 3) {
+        if (Cc > 16) return fail("DownsamplerBlock with 3 input channels supports at most 19 outputs");
+        FirstDownDesc d = {x, sn, sc, sh, sw, w, dst, epi, N, H, W, Cc};
+        first_down_fwd_kernel<<<(unsigned)((Mo + 255) / 256), 256, 0, st>>>(d);
+        CHECK_LAUNCH("first_down_fwd_kernel");
+    } else {
+        if (Cin % 4 || Cout % 4) return fail("DownsamplerBlock: channel counts must be multiples of 4");
+        if (sc != 1 || sw != Cin || sh != (long long)W * Cin || sn != (long long)H * W * Cin)
+            return fail("DownsamplerBlock: input must be NHWC-contiguous");
+        IgemmDesc d;
+        zero_desc(d);
+        d.in = x; d.w = w; d.out = dst; d.epi = epi;
+        d.N = N; d.GH = Ho; d.GW = Wo;
+        d.in_H = H; d.in_W = W; d.in_C = Cin; d.K = Cin; d.ss = 2;
+        d.out_H = Ho; d.out_W = Wo; d.out_C = Cout; d.Nout = Cc;
+        d.gntaps[0] = 9;
+        for (int t = 0; t < 9; ++t) { d.tdh[t] = t / 3 - 1; d.tdw[t] = t % 3 - 1; d.woff[t] = t; }
+        d.wsk = 9; d.wsn = Cin * 9;
+        if (launch_igemm(d, st)) return 1;
+        Epilogue pe = epi;
+        pe.bias = nullptr;
+        PoolDesc p = {x, dst, pe, N, H, W, Cin, Cout, Cc};
+        pool_fwd_kernel<<<grid_for(Mo * (Cin / 4), 256, 1u << 30), 256, 0, st>>>(p);
+        CHECK_LAUNCH("pool_fwd_kernel");
+    }
+    if (two_pass) {
+        if (mode == 2) { if (bn_train_stats(bn, dst, Mo, Cout, ar, st)) return 1; }
+        else if (bn_eval_prepare(bn, Cout, st)) return 1;
+        Epilogue e = kNoEpi;
+        e.bn = mode == 2 ? bn_saved_affine(bn) : bn_eval_affine(bn);
+        e.relu = 1;
+        if (launch_elt(dst, y, e, Mo, Cout, Ho * Wo, st)) return 1;
+    }
+    return 0;
+}
+
+int erf_downsampler_backward(const float *x, long long sn, long long sc, long long sh, long long sw,
+                             const float *w, const erf_bn_t *bn, const float *y, const float *pre,
+                             const float *gy, float *dx, float *dw, float *db, float *dgamma,
+                             float *dbeta, int N, int Cin, int H, int W, int Cout, void *ws,
+                             size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    const int Cc = Cout - Cin, Ho = H / 2, Wo = W / 2;
+    const long long Mo = (long long)N * Ho * Wo;
+    const int mode = bn_mode(bn);
+    float *g = ar.floats((size_t)Mo * Cout);
+    if (!g) return fail("DownsamplerBlock backward: workspace too small");
+    if (mode) {
+        if (bn_backward(bn, pre, gy, y, nullptr, g, dgamma, dbeta, Mo, Cout, Ho * Wo, ar, st)) return 1;
+    } else {
+        if (launch_mask(gy, y, g, Mo, Cout, st)) return 1;
+    }
+    if (Cin == 3) {
+        const int nw = Cc * 27;
+        long long nsplit = (Mo + 2047) / 2048;
+        if (nsplit > 1024) nsplit = 1024;
+        long long sp = (Mo + nsplit - 1) / nsplit;
+        sp = (sp + 63) / 64 * 64;
+        nsplit = (Mo + sp - 1) / sp;
+        float *partial = ar.floats((size_t)nsplit * (nw + Cc));
+        if (!partial) return fail("DownsamplerBlock backward: workspace too small");
+        FirstDownWgradDesc d = {x, sn, sc, sh, sw, g, partial, N, H, W, Cc, Cout, (int)sp};
+        first_down_wgrad_kernel<<<(unsigned)nsplit, 512, 0, st>>>(d);
+        CHECK_LAUNCH("first_down_wgrad_kernel");
+        reduce_flat_kernel<<<(nw + Cc + 255) / 256, 256, 0, st>>>(partial, dw, db, (int)nsplit, nw, Cc);
+        CHECK_LAUNCH("reduce_flat_kernel");
+    } else {
+        WgradDesc d;
+        memset(&d, 0, sizeof(d));
+        d.in = x; d.g = g;
+        d.N = N; d.GH = Ho; d.GW = Wo;
+        d.in_H = H; d.in_W = W; d.in_C = Cin; d.K = Cin; d.ss = 2; d.os = 1; d.ntaps = 9;
+        int woff[9];
+        for (int t = 0; t < 9; ++t) { d.tdh[t] = t / 3 - 1; d.tdw[t] = t % 3 - 1; woff[t] = t; }
+        d.g_H = Ho; d.g_W = Wo; d.g_C = Cout; d.Nout = Cc;
+        if (launch_wgrad(d, dw, db, woff, 9, Cin * 9, 1u, ar, st)) return 1;
+    }
+    if (dx) {
+        // dx is NHWC [N,H,W,Cin]: max-pool gradient first, then the conv data gradient on top.
+        PoolBwdDesc p;
+        p.in = x; p.g = g; p.dx = dx; p.N = N; p.H = H; p.W = W; p.C = Cin; p.g_C = Cout; p.g_coff = Cc;
+        if (Cin == 3 && (sc != 1 || sw != Cin || sh != (long long)W * Cin || sn != (long long)H * W * Cin))
+            return fail("DownsamplerBlock backward: dx for a 3-channel input needs an NHWC input");
+        pool_bwd_kernel<<<grid_for(Mo * Cin, 256, 1u << 30), 256, 0, st>>>(p);
+        CHECK_LAUNCH("pool_bwd_kernel");
+        const ParityTaps pt = parity_taps();
+        IgemmDesc d;
+        zero_desc(d);
+        d.in = g; d.w = w; d.out = dx;
+        d.epi.res = dx; d.epi.res_C = Cin; d.epi.res_coff = 0;
+        d.N = N; d.GH = Ho; d.GW = Wo;
+        d.in_H = Ho; d.in_W = Wo; d.in_C = Cout; d.in_coff = 0; d.K = Cc; d.ss = 1;
+        d.out_H = H; d.out_W = W; d.out_C = Cin; d.Nout = Cin; d.os = 2;
+        d.ngroups = 4;
+        for (int gq = 0; gq < 4; ++gq) {
+            d.gtap0[gq] = pt.gtap0[gq]; d.gntaps[gq] = pt.gntaps[gq]; d.goa[gq] = pt.goa[gq]; d.gob[gq] = pt.gob[gq];
+        }
+        for (int t = 0; t < 9; ++t) { d.tdh[t] = pt.dh[t]; d.tdw[t] = pt.dw[t]; d.woff[t] = pt.kh[t] * 3 + pt.kw[t]; }
+        d.wsk = Cin * 9; d.wsn = 9;   // W[co][ci][kh][kw]: k = co, j = ci
+        if (launch_igemm(d, st)) return 1;
+    }
+    return 0;
+}
+
+// ================================================================================ non_bottleneck_1d
+int erf_nb1d_forward(const float *x, const float *const w[4], const float *const b[4],
+                     const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil, float *y,
+                     float *const save[5], int N, int C, int H, int W, void *ws, size_t ws_bytes,
+                     void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (C % 4) return fail("non_bottleneck_1d: chann must be a multiple of 4 (got %d)", C);
+    if (dil < 1) return fail("non_bottleneck_1d: dilation must be >= 1");
+    const long long M = (long long)N * H * W;
+    const size_t nel = (size_t)M * C;
+    const int m1 = bn_mode(bn1), m2 = bn_mode(bn2);
+    // Two-pass BatchNorm (conv -> pre, [statistics,] normalise) in train mode and whenever the
+    // activations are saved for backward; eval-mode inference folds BN into the conv epilogue.
+    const bool tp1 = m1 == 2 || (m1 == 1 && save), tp2 = m2 == 2 || (m2 == 1 && save);
+    float *t1, *p2, *t2, *t3, *p4;
+    if (save) {
+        t1 = save[0]; p2 = save[1]; t2 = save[2]; t3 = save[3]; p4 = save[4];
+        if ((m1 && !p2) || (m2 && !p4)) return fail("non_bottleneck_1d: BatchNorm needs the pre2/pre4 buffers");
+    } else {
+        float *a = ar.floats(nel), *c = ar.floats(nel);
+        if (!a || !c) return fail("non_bottleneck_1d: workspace too small");
+        t1 = a; p2 = c; t2 = c; t3 = a; p4 = c;
+    }
+    IgemmDesc d;
+    // conv3x1_1 + ReLU
+    conv1d_desc(d, x, w[0], t1, N, C, H, W, 0, 1, false);
+    d.epi.bias = b[0]; d.epi.relu = 1;
+    if (launch_igemm(d, st)) return 1;
+    // conv1x3_1 [+ BN1] + ReLU
+    conv1d_desc(d, t1, w[1], tp1 ? p2 : t2, N, C, H, W, 1, 1, false);
+    d.epi.bias = b[1];
+    if (!tp1) {
+        if (m1 == 1) d.epi.bn = bn_eval_affine(bn1);
+        d.epi.relu = 1;
+    }
+    if (launch_igemm(d, st)) return 1;
+    if (tp1) {
+        if (m1 == 2) { if (bn_train_stats(bn1, p2, M, C, ar, st)) return 1; }
+        else if (bn_eval_prepare(bn1, C, st)) return 1;
+        Epilogue e = kNoEpi;
+        e.bn = m1 == 2 ? bn_saved_affine(bn1) : bn_eval_affine(bn1);
+        e.relu = 1;
+        if (launch_elt(p2, t2, e, M, C, H * W, st)) return 1;
+    }
+    // conv3x1_2 (dilated) + ReLU
+    conv1d_desc(d, t2, w[2], t3, N, C, H, W, 0, dil, false);
+    d.epi.bias = b[2]; d.epi.relu = 1;
+    if (launch_igemm(d, st)) return 1;
+    // conv1x3_2 (dilated) [+ BN2] [+ dropout] + residual + ReLU
+    conv1d_desc(d, t3, w[3], tp2 ? p4 : y, N, C, H, W, 1, dil, false);
+    d.epi.bias = b[3];
+    if (!tp2) {
+        if (m2 == 1) d.epi.bn = bn_eval_affine(bn2);
+        d.epi.nscale = drop_scale;
+        d.epi.res = x; d.epi.res_C = C; d.epi.res_coff = 0;
+        d.epi.relu = 1;
+    }
+    if (launch_igemm(d, st)) return 1;
+    if (tp2) {
+        if (m2 == 2) { if (bn_train_stats(bn2, p4, M, C, ar, st)) return 1; }
+        else if (bn_eval_prepare(bn2, C, st)) return 1;
+        Epilogue e = kNoEpi;
+        e.bn = m2 == 2 ? bn_saved_affine(bn2) : bn_eval_affine(bn2);
+        e.nscale = drop_scale;
+        e.res = x; e.res_C = C; e.res_coff = 0;
+        e.relu = 1;
+        if (launch_elt(p4, y, e, M, C, H * W, st)) return 1;
+    }
+    return 0;
+}
+
+int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
+                      const float *drop_scale, int dil, const float *y, const float *const save[5],
+                      const float *gy, float *dx, float *const dw[4], float *const db[4],
+                      float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, void *ws,
+                      size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (C % 4) return fail("non_bottleneck_1d: chann must be a multiple of 4 (got %d)", C);
+    if (!save) return fail("non_bottleneck_1d backward needs the saved activations");
+    const long long M = (long long)N * H * W;
+    const size_t nel = (size_t)M * C;
+    const int m1 = bn_mode(bn1), m2 = bn_mode(bn2);
+    const float *t1 = save[0], *p2 = save[1], *t2 = save[2], *t3 = save[3], *p4 = save[4];
+    float *g4 = ar.floats(nel), *ga = ar.floats(nel), *gb = ar.floats(nel);
+    if (!g4 || !ga || !gb) return fail("non_bottleneck_1d backward: workspace too small");
+    const size_t ws_mark = ar.off;
+    const int woff[3] = {0, 1, 2};
+    IgemmDesc d;
+    WgradDesc wd;
+
+    // g4 = gy * (y > 0): gradient of the residual sum (goes to x unchanged and into the conv branch)
+    if (launch_mask(gy, y, g4, M, C, st)) return 1;
+    const float *gin = g4;          // gradient w.r.t. the conv1x3_2 output
+    if (m2) {
+        if (bn_backward(bn2, p4, g4, nullptr, drop_scale, ga, dgamma ? dgamma[1] : nullptr,
+                        dbeta ? dbeta[1] : nullptr, M, C, H * W, ar, st)) return 1;
+        gin = ga;
+    } else if (drop_scale) {
+        Epilogue e = kNoEpi;
+        e.nscale = drop_scale;
+        if (launch_elt(g4, ga, e, M, C, H * W, st)) return 1;
+        gin = ga;
+    }
+    // conv1x3_2: weight gradient from (t3, gin); data gradient masked by t3 > 0
+    ar.off = ws_mark;
+    wgrad1d_desc(wd, t3, gin, N, C, H, W, 1, dil);
+    if (launch_wgrad(wd, dw[3], db[3], woff, 3, C * 3, 1u, ar, st)) return 1;
+    conv1d_desc(d, gin, w[3], gb, N, C, H, W, 1, dil, true);
+    d.epi.mask = t3; d.epi.mask_C = C;
+    if (launch_igemm(d, st)) return 1;
+    // conv3x1_2: (t2, gb) -> ga masked by t2 > 0
+    ar.off = ws_mark;
+    wgrad1d_desc(wd, t2, gb, N, C, H, W, 0, dil);
+    if (launch_wgrad(wd, dw[2], db[2], woff, 3, C * 3, 1u, ar, st)) return 1;
+    conv1d_desc(d, gb, w[2], ga, N, C, H, W, 0, dil, true);
+    d.epi.mask = t2; d.epi.mask_C = C;
+    if (launch_igemm(d, st)) return 1;
+    const float *g2 = ga;
+    float *g1 = gb;
+    if (m1) {
+        ar.off = ws_mark;
+        if (bn_backward(bn1, p2, ga, nullptr, nullptr, gb, dgamma ? dgamma[0] : nullptr,
+                        dbeta ? dbeta[0] : nullptr, M, C, H * W, ar, st)) return 1;
+        g2 = gb;
+        g1 = ga;
+    }
+    // conv1x3_1: (t1, g2) -> g1 masked by t1 > 0
+    ar.off = ws_mark;
+    wgrad1d_desc(wd, t1, g2, N, C, H, W, 1, 1);
+    if (launch_wgrad(wd, dw[1], db[1], woff, 3, C * 3, 1u, ar, st)) return 1;
+    conv1d_desc(d, g2, w[1], g1, N, C, H, W, 1, 1, true);
+    d.epi.mask = t1; d.epi.mask_C = C;
+    if (launch_igemm(d, st)) return 1;
+    // conv3x1_1: (x, g1) -> dx = dgrad + g4
+    ar.off = ws_mark;
+    wgrad1d_desc(wd, x, g1, N, C, H, W, 0, 1);
+    if (launch_wgrad(wd, dw[0], db[0], woff, 3, C * 3, 1u, ar, st)) return 1;
+    conv1d_desc(d, g1, w[0], dx, N, C, H, W, 0, 1, true);
+    d.epi.res = g4; d.epi.res_C = C;
+    if (launch_igemm(d, st)) return 1;
+    return 0;
+}
+
+// ================================================================================ Upsampler
+int erf_upsampler_forward(const float *x, const float *w, const float *b, const erf_bn_t *bn, float *y,
+                          float *pre, int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes,
+                          void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (Cin % 4 || Cout % 4) return fail("UpsamplerBlock: channel counts must be multiples of 4");
+    const int mode = bn_mode(bn);
+    const long long Mo = (long long)N * 4 * H * W;
+    const bool two_pass = mode == 2 || (mode == 1 && pre);
+    float *dst = two_pass ? pre : y;
+    if (two_pass && !pre) {
+        dst = ar.floats((size_t)Mo * Cout);
+        if (!dst) return fail("UpsamplerBlock: workspace too small");
+    }
+    const ParityTaps pt = parity_taps();
+    IgemmDesc d;
+    zero_desc(d);
+    d.in = x; d.w = w; d.out = dst;
+    d.epi.bias = b;
+    if (mode == 1 && !two_pass) d.epi.bn = bn_eval_affine(bn);
+    d.epi.relu = !two_pass;
+    d.N = N; d.GH = H; d.GW = W;
+    d.in_H = H; d.in_W = W; d.in_C = Cin; d.K = Cin; d.ss = 1;
+    d.out_H = 2 * H; d.out_W = 2 * W; d.out_C = Cout; d.Nout = Cout; d.os = 2;
+    d.ngroups = 4;
+    for (int g = 0; g < 4; ++g) {
+        d.gtap0[g] = pt.gtap0[g]; d.gntaps[g] = pt.gntaps[g]; d.goa[g] = pt.goa[g]; d.gob[g] = pt.gob[g];
+    }
+    for (int t = 0; t < 9; ++t) { d.tdh[t] = pt.dh[t]; d.tdw[t] = pt.dw[t]; d.woff[t] = pt.kh[t] * 3 + pt.kw[t]; }
+    d.wsk = Cout * 9; d.wsn = 9;       // W[ci][co][kh][kw]: k = ci, j = co
+    if (launch_igemm(d, st)) return 1;
+    if (two_pass) {
+        if (mode == 2) { if (bn_train_stats(bn, dst, Mo, Cout, ar, st)) return 1; }
+        else if (bn_eval_prepare(bn, Cout, st)) return 1;
+        Epilogue e = kNoEpi;
+        e.bn = mode == 2 ? bn_saved_affine(bn) : bn_eval_affine(bn);
+        e.relu = 1;
+        if (launch_elt(dst, y, e, Mo, Cout, 4 * H * W, st)) return 1;
+    }
+    return 0;
+}
+
+int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, const float *y,
+                           const float *pre, const float *gy, float *dx, float *dw, float *db,
+                           float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout, void *ws,
+                           size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    const int mode = bn_mode(bn);
+    const long long Mo = (long long)N * 4 * H * W;
+    float *g = ar.floats((size_t)Mo * Cout);
+    if (!g) return fail("UpsamplerBlock backward: workspace too small");
+    if (mode) {
+        if (bn_backward(bn, pre, gy, y, nullptr, g, dgamma, dbeta, Mo, Cout, 4 * H * W, ar, st)) return 1;
+    } else {
+        if (launch_mask(gy, y, g, Mo, Cout, st)) return 1;
+    }
+    const ParityTaps pt = parity_taps();
+    {   // weight gradient over the parity classes
+        WgradDesc d;
+        memset(&d, 0, sizeof(d));
+        d.in = x; d.g = g;
+        d.N = N; d.GH = H; d.GW = W;
+        d.in_H = H; d.in_W = W; d.in_C = Cin; d.K = Cin; d.ss = 1; d.os = 2; d.ntaps = 9;
+        int woff[9];
+        for (int t = 0; t < 9; ++t) {
+            d.tdh[t] = pt.dh[t]; d.tdw[t] = pt.dw[t]; d.toa[t] = pt.oa[t]; d.tob[t] = pt.ob[t];
+            woff[t] = pt.kh[t] * 3 + pt.kw[t];
+        }
+        d.g_H = 2 * H; d.g_W = 2 * W; d.g_C = Cout; d.Nout = Cout;
+        if (launch_wgrad(d, dw, db, woff, Cout * 9, 9, pt.rep_mask, ar, st)) return 1;
+    }
+    if (dx) {   // data gradient = ordinary 3x3 stride-2 convolution of g
+        IgemmDesc d;
+        zero_desc(d);
+        d.in = g; d.w = w; d.out = dx;
+        d.N = N; d.GH = H; d.GW = W;
+        d.in_H = 2 * H; d.in_W = 2 * W; d.in_C = Cout; d.K = Cout; d.ss = 2;
+        d.out_H = H; d.out_W = W; d.out_C = Cin; d.Nout = Cin;
+        d.gntaps[0] = 9;
+        for (int t = 0; t < 9; ++t) { d.tdh[t] = t / 3 - 1; d.tdw[t] = t % 3 - 1; d.woff[t] = t; }
+        d.wsk = 9; d.wsn = Cout * 9;   // W[ci][co][kh][kw]: k = co, j = ci
+        if (launch_igemm(d, st)) return 1;
+    }
+    return 0;
+}
+
+// ================================================================================ output conv
+int erf_outconv_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin, int H,
+                        int W, int ncls, int softmax, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin != OC_CIN) return fail("output ConvTranspose2d: Cin must be %d (got %d)", OC_CIN, Cin);
+    if (ncls < 1 || ncls > OC_MAX_NCLS) return fail("output ConvTranspose2d: 1 <= classes <= %d", OC_MAX_NCLS);
+    if (!aligned16(x) || ((uintptr_t)y & 7)) return fail("output ConvTranspose2d: misaligned tensors");
+    const long long M = (long long)N * H * W;
+    OutConvDesc d = {x, w, b, y, N, H, W, ncls};
+    if (softmax) outconv_fwd_kernel<true><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
+    else outconv_fwd_kernel<false><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
+    CHECK_LAUNCH("outconv_fwd_kernel");
+    return 0;
+}
+
+int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw, float *db,
+                         int N, int Cin, int H, int W, int ncls, void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (Cin != OC_CIN) return fail("output ConvTranspose2d: Cin must be %d (got %d)", OC_CIN, Cin);
+    if (ncls < 1 || ncls > OC_MAX_NCLS) return fail("output ConvTranspose2d: 1 <= classes <= %d", OC_MAX_NCLS);
+    const long long M = (long long)N * H * W;
+    const int nab = ncls * 4, slab = nab * OC_CIN + nab;
+    long long nsplit = (M + 1023) / 1024;
+    if (nsplit > 1024) nsplit = 1024;
+    long long sp = (M + nsplit - 1) / nsplit;
+    sp = (sp + 63) / 64 * 64;
+    nsplit = (M + sp - 1) / sp;
+    float *partial = ar.floats((size_t)nsplit * slab);
+    if (!partial) return fail("output ConvTranspose2d backward: workspace too small");
+    OutConvBwdDesc d = {x, w, gy, dx, partial, N, H, W, ncls, (int)sp};
+    if (dx) {
+        outconv_dgrad_kernel<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
+        CHECK_LAUNCH("outconv_dgrad_kernel");
+    }
+    outconv_wgrad_kernel<<<(unsigned)nsplit, 512, 0, st>>>(d);
+    CHECK_LAUNCH("outconv_wgrad_kernel");
+    outconv_wreduce_kernel<<<(slab + 255) / 256, 256, 0, st>>>(partial, dw, db, (int)nsplit, ncls);
+    CHECK_LAUNCH("outconv_wreduce_kernel");
+    return 0;
+}
+
+// ================================================================================ plain Conv2d
+static void conv2d_taps(int k, int *dh, int *dw, int *woff, bool transpose)
+{
+    const int r = (k - 1) / 2;
+    for (int t = 0; t < k * k; ++t) {
+        const int a = t / k - r, b = t % k - r;
+        dh[t] = transpose ? -a : a;
+        dw[t] = transpose ? -b : b;
+        woff[t] = t;
+    }
+}
+
+int erf_conv2d_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin, int H,
+                       int W, int Cout, int k, int relu, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (k != 1 && k != 3) return fail("conv2d: kernel size must be 1 or 3");
+    IgemmDesc d;
+    zero_desc(d);
+    d.in = x; d.w = w; d.out = y;
+    d.epi.bias = b; d.epi.relu = relu;
+    d.N = N; d.GH = H; d.GW = W;
+    d.in_H = H; d.in_W = W; d.in_C = Cin; d.K = Cin;
+    d.out_H = H; d.out_W = W; d.out_C = Cout; d.Nout = Cout;
+    d.gntaps[0] = k * k;
+    conv2d_taps(k, d.tdh, d.tdw, d.woff, false);
+    d.wsk = k * k; d.wsn = Cin * k * k;
+    return launch_igemm(d, st);
+}
+
+int erf_conv2d_backward(const float *x, const float *w, const float *y, const float *gy, float *dx,
+                        float *dw, float *db, int N, int Cin, int H, int W, int Cout, int k, int relu,
+                        void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (k != 1 && k != 3) return fail("conv2d: kernel size must be 1 or 3");
+    const long long M = (long long)N * H * W;
+    const float *g = gy;
+    if (relu) {
+        if (Cout % 4) return fail("conv2d backward with ReLU needs Cout %% 4 == 0");
+        float *gm = ar.floats((size_t)M * Cout);
+        if (!gm) return fail("conv2d backward: workspace too small");
+        if (launch_mask(gy, y, gm, M, Cout, st)) return 1;
+        g = gm;
+    }
+    WgradDesc wd;
+    memset(&wd, 0, sizeof(wd));
+    wd.in = x; wd.g = g;
+    wd.N = N; wd.GH = H; wd.GW = W;
+    wd.in_H = H; wd.in_W = W; wd.in_C = Cin; wd.K = Cin; wd.ss = 1; wd.os = 1; wd.ntaps = k * k;
+    int woff[9];
+    conv2d_taps(k, wd.tdh, wd.tdw, woff, false);
+    wd.g_H = H; wd.g_W = W; wd.g_C = Cout; wd.Nout = Cout;
+    if (launch_wgrad(wd, dw, db, woff, k * k, Cin * k * k, 1u, ar, st)) return 1;
+    if (dx) {
+        IgemmDesc d;
+        zero_desc(d);
+        d.in = g; d.w = w; d.out = dx;
+        d.N = N; d.GH = H; d.GW = W;
+        d.in_H = H; d.in_W = W; d.in_C = Cout; d.K = Cout;
+        d.out_H = H; d.out_W = W; d.out_C = Cin; d.Nout = Cin;
+        d.gntaps[0] = k * k;
+        conv2d_taps(k, d.tdh, d.tdw, d.woff, true);
+        d.wsk = Cin * k * k; d.wsn = k * k;
+        if (launch_igemm(d, st)) return 1;
+    }
+    return 0;
+}
+
+}  // extern "C"

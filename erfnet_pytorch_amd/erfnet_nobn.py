@@ -1,0 +1,56 @@
+"""Drop-in for the reference's ``eval/erfnet_nobn.py`` (the model ``eval_forwardTime.py`` times):
+same module tree and state_dict as ``erfnet.py`` but BatchNorm and dropout are never applied."""
+import torch.nn as nn
+
+try:
+    from . import _nets
+except ImportError:
+    from erfnet_pytorch_amd import _nets
+
+DownsamplerBlock = _nets.PlainDownsamplerBlock
+non_bottleneck_1d = _nets.PlainNonBottleneck1d
+UpsamplerBlock = _nets.PlainUpsamplerBlock
+
+
+class Encoder(nn.Module):
+    """reference eval/erfnet_nobn.py:66-98"""
+
+    def __init__(self, num_classes):
+        super().__init__()
+        self.initial_block = DownsamplerBlock(3, 16)
+        self.layers = nn.ModuleList(_nets.eval_encoder_layers(DownsamplerBlock, non_bottleneck_1d, 0.1))
+        self.output_conv = nn.Conv2d(128, num_classes, 1, stride=1, padding=0, bias=True)
+
+    def forward(self, input, predict=False):
+        t = self.initial_block(input)
+        for layer in self.layers:
+            t = layer(t)
+        return _nets.conv1x1(self.output_conv, t) if predict else t
+
+
+class Decoder(nn.Module):
+    """reference eval/erfnet_nobn.py:112-136"""
+
+    def __init__(self, num_classes):
+        super().__init__()
+        self.layers = nn.ModuleList(_nets.eval_decoder_layers(UpsamplerBlock, non_bottleneck_1d))
+        self.output_conv = _nets.OutputConvTranspose(16, num_classes)
+
+    def forward(self, input):
+        for layer in self.layers:
+            input = layer(input)
+        return self.output_conv(input)
+
+
+class ERFNet(nn.Module):
+    """reference eval/erfnet_nobn.py:139-155"""
+
+    def __init__(self, num_classes, encoder=None):
+        super().__init__()
+        self.encoder = Encoder(num_classes) if encoder is None else encoder
+        self.decoder = Decoder(num_classes)
+
+    def forward(self, input, only_encode=False):
+        if only_encode:
+            return self.encoder.forward(input, predict=True)
+        return self.decoder.forward(self.encoder(input))

@@ -1,0 +1,386 @@
+"""``torch.autograd.Function`` wrappers over the C ABI of ``liberfnet_hip.so``.
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd graph; every number a
+GPU tensor receives is computed by the HIP kernels.  Activations are kept NHWC in memory (logical
+shape stays [N,C,H,W], i.e. ``torch.channels_last``); the classifier logits leave the output
+transposed convolution NCHW-contiguous so that torch's loss / argmax read them directly.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BnStruct, vp
+
+_workspaces = {}
+
+
+def _dev_ctx(t):
+    return torch.cuda.device(t.device)
+
+
+def _stream(t):
+    return vp(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _workspace(t, n_pixels, max_c):
+    """Scratch buffer for one call, cached per (device, stream); stream order keeps reuse safe."""
+    need = _lib.lib().erf_workspace_bytes(int(n_pixels), int(max_c))
+    key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < need:
+        buf = None
+        _workspaces.pop(key, None)
+        buf = torch.empty(int(need * 1.25), dtype=torch.uint8, device=t.device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _p(t):
+    return None if t is None else vp(t.data_ptr())
+
+
+def _is_nhwc_dense(x):
+    return x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _nhwc(x):
+    """Dense NHWC fp32 view/copy of a logical-NCHW tensor."""
+    if x.dtype != torch.float32:
+        raise TypeError(f"erfnet_hip kernels compute in fp32, got {x.dtype}")
+    if _is_nhwc_dense(x):
+        return x
+    out = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    out.copy_(x)
+    return out
+
+
+def _empty_nhwc(n, c, h, w, like):
+    return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device,
+                       memory_format=torch.channels_last)
+
+
+def _param(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError("parameters must be fp32")
+    return t.detach().contiguous()
+
+
+class _Bn:
+    """Per-call BatchNorm state handed to the library (mode 0 = off, 1 = eval, 2 = train)."""
+
+    def __init__(self, mode, gamma, beta, running_mean, running_var, momentum, eps, need_save,
+                 saved=None):
+        self.mode = int(mode)
+        self.gamma, self.beta = _param(gamma), _param(beta)
+        self.rm, self.rv = running_mean, running_var
+        self.momentum, self.eps = float(momentum), float(eps)
+        self.save_mean = self.save_invstd = None
+        if saved is not None:
+            self.save_mean, self.save_invstd = saved
+        elif self.mode and need_save:
+            c = gamma.numel()
+            self.save_mean = torch.empty(c, dtype=torch.float32, device=gamma.device)
+            self.save_invstd = torch.empty(c, dtype=torch.float32, device=gamma.device)
+        self.struct = BnStruct(self.mode, _p(self.gamma), _p(self.beta), _p(self.rm), _p(self.rv),
+                               _p(self.save_mean), _p(self.save_invstd), self.momentum, self.eps)
+
+    def ref(self):
+        return C.byref(self.struct) if self.mode else None
+
+
+def _arr(ts):
+    return (vp * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+# ------------------------------------------------------------------------------ DownsamplerBlock
+class _Downsampler(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, mode, momentum, eps):
+        lib = _lib.lib()
+        n, cin, h, wd = x.shape
+        cout = w.shape[0] + cin
+        if cin != 3:
+            x = _nhwc(x)
+        elif x.dtype != torch.float32:
+            raise TypeError("erfnet_hip kernels compute in fp32")
+        need = any(ctx.needs_input_grad)
+        bn = _Bn(mode, gamma, beta, rm, rv, momentum, eps, need)
+        wq, bq = _param(w), _param(b)
+        if h % 2 or wd % 2:
+            raise RuntimeError(f"DownsamplerBlock needs even H and W, got {h}x{wd} (the reference "
+                               "fails in torch.cat)")
+        y = _empty_nhwc(n, cout, h // 2, wd // 2, x)
+        pre = torch.empty_like(y) if (mode and need) else None
+        ws = _workspace(x, n * (h // 2) * (wd // 2), cout)
+        sn, sc, sh, sw = x.stride()
+        with _dev_ctx(x):
+            _lib.check(lib.erf_downsampler_forward(_p(x), sn, sc, sh, sw, _p(wq), _p(bq), bn.ref(),
+                                                   _p(y), _p(pre), n, cin, h, wd, cout, _p(ws),
+                                                   ws.numel(), _stream(x)))
+        if need:
+            ctx.save_for_backward(x, wq, y, pre, bn.gamma, bn.save_mean, bn.save_invstd)
+            ctx.cfg = (mode, momentum, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        x, wq, y, pre, gamma, smean, sinv = ctx.saved_tensors
+        mode, momentum, eps = ctx.cfg
+        n, cin, h, wd = x.shape
+        cout = y.shape[1]
+        gy = _nhwc(gy)
+        bn = _Bn(mode, gamma, None, None, None, momentum, eps, False, saved=(smean, sinv))
+        need_dx = ctx.needs_input_grad[0]
+        if need_dx and cin == 3 and not _is_nhwc_dense(x):
+            raise RuntimeError("gradient w.r.t. a 3-channel input needs a channels_last input")
+        dx = _empty_nhwc(n, cin, h, wd, x) if need_dx else None
+        dw = torch.empty_like(wq)
+        db = torch.empty(wq.shape[0], dtype=torch.float32, device=x.device)
+        dg = torch.empty(cout, dtype=torch.float32, device=x.device) if mode else None
+        dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if mode else None
+        ws = _workspace(x, n * (h // 2) * (wd // 2), cout)
+        sn, sc, sh, sw = x.stride()
+        with _dev_ctx(x):
+            _lib.check(lib.erf_downsampler_backward(_p(x), sn, sc, sh, sw, _p(wq), bn.ref(), _p(y),
+                                                    _p(pre), _p(gy), _p(dx), _p(dw), _p(db), _p(dg),
+                                                    _p(dbt), n, cin, h, wd, cout, _p(ws), ws.numel(),
+                                                    _stream(x)))
+        return dx, dw, db, dg, dbt, None, None, None, None, None
+
+
+def downsampler(x, w, b, bn_weight=None, bn_bias=None, running_mean=None, running_var=None,
+                bn_mode=0, momentum=0.1, eps=1e-3):
+    """DownsamplerBlock.forward of the reference (train/erfnet_blocks.py:25-29) on the GPU."""
+    return _Downsampler.apply(x, w, b, bn_weight if bn_mode else None, bn_bias if bn_mode else None,
+                              running_mean, running_var, bn_mode, momentum, eps)
+
+
+# ------------------------------------------------------------------------------ non_bottleneck_1d
+class _Nb1d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, w2, b2, w3, b3, g1, be1, g2, be2, rm1, rv1, rm2, rv2,
+                drop_scale, dil, mode, momentum, eps):
+        lib = _lib.lib()
+        x = _nhwc(x)
+        n, c, h, wd = x.shape
+        need = any(ctx.needs_input_grad)
+        ws_ = [_param(t) for t in (w0, w1, w2, w3)]
+        bs_ = [_param(t) for t in (b0, b1, b2, b3)]
+        bn1 = _Bn(mode, g1, be1, rm1, rv1, momentum, eps, need)
+        bn2 = _Bn(mode, g2, be2, rm2, rv2, momentum, eps, need)
+        ds = None if drop_scale is None else drop_scale.to(torch.float32).contiguous()
+        y = torch.empty_like(x)
+        save = None
+        if need:
+            t1, t2, t3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            p2 = torch.empty_like(x) if mode else None
+            p4 = torch.empty_like(x) if mode else None
+            save = [t1, p2, t2, t3, p4]
+        ws = _workspace(x, n * h * wd, c)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_nb1d_forward(_p(x), _arr(ws_), _arr(bs_), bn1.ref(), bn2.ref(), _p(ds),
+                                            int(dil), _p(y), None if save is None else _arr(save),
+                                            n, c, h, wd, _p(ws), ws.numel(), _stream(x)))
+        if need:
+            ctx.save_for_backward(x, y, *save, *ws_, bn1.gamma, bn2.gamma, bn1.save_mean,
+                                  bn1.save_invstd, bn2.save_mean, bn2.save_invstd, ds)
+            ctx.cfg = (int(dil), mode, momentum, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        (x, y, t1, p2, t2, t3, p4, w0, w1, w2, w3, g1, g2, sm1, si1, sm2, si2, ds) = ctx.saved_tensors
+        dil, mode, momentum, eps = ctx.cfg
+        n, c, h, wd = x.shape
+        gy = _nhwc(gy)
+        bn1 = _Bn(mode, g1, None, None, None, momentum, eps, False, saved=(sm1, si1))
+        bn2 = _Bn(mode, g2, None, None, None, momentum, eps, False, saved=(sm2, si2))
+        dx = torch.empty_like(x)
+        dws = [torch.empty_like(w) for w in (w0, w1, w2, w3)]
+        dbs = [torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(4)]
+        if mode:
+            dgs = [torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(2)]
+            dbts = [torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(2)]
+        else:
+            dgs = dbts = [None, None]
+        ws = _workspace(x, n * h * wd, c)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_nb1d_backward(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
+                                             dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
+                                             _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
+                                             _p(ws), ws.numel(), _stream(x)))
+        return (dx, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dws[3], dbs[3],
+                dgs[0], dbts[0], dgs[1], dbts[1], None, None, None, None, None, None, None, None, None)
+
+
+def nb1d(x, weights, biases, dilated, bn1=None, bn2=None, bn_mode=0, drop_scale=None, momentum=0.1,
+         eps=1e-3):
+    """non_bottleneck_1d.forward of the reference (train/erfnet_blocks.py:55-73) on the GPU.
+
+    weights / biases: conv3x1_1, conv1x3_1, conv3x1_2, conv1x3_2.  bn1 / bn2: (weight, bias,
+    running_mean, running_var) tuples, used when bn_mode != 0.  drop_scale: [N, C] factors
+    (0 or 1/(1-p)) standing for nn.Dropout2d, or None.
+    """
+    g1 = be1 = rm1 = rv1 = g2 = be2 = rm2 = rv2 = None
+    if bn_mode:
+        g1, be1, rm1, rv1 = bn1
+        g2, be2, rm2, rv2 = bn2
+    return _Nb1d.apply(x, weights[0], biases[0], weights[1], biases[1], weights[2], biases[2],
+                       weights[3], biases[3], g1, be1, g2, be2, rm1, rv1, rm2, rv2, drop_scale,
+                       dilated, bn_mode, momentum, eps)
+
+
+# ------------------------------------------------------------------------------ UpsamplerBlock
+class _Upsampler(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, mode, momentum, eps):
+        lib = _lib.lib()
+        x = _nhwc(x)
+        n, cin, h, wd = x.shape
+        cout = w.shape[1]
+        need = any(ctx.needs_input_grad)
+        bn = _Bn(mode, gamma, beta, rm, rv, momentum, eps, need)
+        wq, bq = _param(w), _param(b)
+        y = _empty_nhwc(n, cout, 2 * h, 2 * wd, x)
+        pre = torch.empty_like(y) if (mode and need) else None
+        ws = _workspace(x, n * 4 * h * wd, max(cin, cout))
+        with _dev_ctx(x):
+            _lib.check(lib.erf_upsampler_forward(_p(x), _p(wq), _p(bq), bn.ref(), _p(y), _p(pre), n, cin,
+                                                 h, wd, cout, _p(ws), ws.numel(), _stream(x)))
+        if need:
+            ctx.save_for_backward(x, wq, y, pre, bn.gamma, bn.save_mean, bn.save_invstd)
+            ctx.cfg = (mode, momentum, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        x, wq, y, pre, gamma, smean, sinv = ctx.saved_tensors
+        mode, momentum, eps = ctx.cfg
+        n, cin, h, wd = x.shape
+        cout = y.shape[1]
+        gy = _nhwc(gy)
+        bn = _Bn(mode, gamma, None, None, None, momentum, eps, False, saved=(smean, sinv))
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(wq)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device)
+        dg = torch.empty(cout, dtype=torch.float32, device=x.device) if mode else None
+        dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if mode else None
+        ws = _workspace(x, n * 4 * h * wd, max(cin, cout))
+        with _dev_ctx(x):
+            _lib.check(lib.erf_upsampler_backward(_p(x), _p(wq), bn.ref(), _p(y), _p(pre), _p(gy), _p(dx),
+                                                  _p(dw), _p(db), _p(dg), _p(dbt), n, cin, h, wd, cout,
+                                                  _p(ws), ws.numel(), _stream(x)))
+        return dx, dw, db, dg, dbt, None, None, None, None, None
+
+
+def upsampler(x, w, b, bn_weight=None, bn_bias=None, running_mean=None, running_var=None, bn_mode=0,
+              momentum=0.1, eps=1e-3):
+    """UpsamplerBlock.forward of the reference (train/erfnet_blocks.py:84-88) on the GPU."""
+    return _Upsampler.apply(x, w, b, bn_weight if bn_mode else None, bn_bias if bn_mode else None,
+                            running_mean, running_var, bn_mode, momentum, eps)
+
+
+# ------------------------------------------------------------------------------ output ConvTranspose2d
+class _OutConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        lib = _lib.lib()
+        x = _nhwc(x)
+        n, cin, h, wd = x.shape
+        ncls = w.shape[1]
+        wq, bq = _param(w), _param(b)
+        y = torch.empty((n, ncls, 2 * h, 2 * wd), dtype=torch.float32, device=x.device)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_outconv_forward(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, ncls, 0,
+                                               _stream(x)))
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, wq)
+            ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        x, wq = ctx.saved_tensors
+        n, cin, h, wd = x.shape
+        ncls = wq.shape[1]
+        gy = gy.contiguous()
+        if gy.dtype != torch.float32:
+            raise TypeError("erfnet_hip kernels compute in fp32")
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(wq)
+        db = torch.empty(ncls, dtype=torch.float32, device=x.device)
+        ws = _workspace(x, n * h * wd, 16)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_outconv_backward(_p(x), _p(wq), _p(gy), _p(dx), _p(dw), _p(db), n, cin, h,
+                                                wd, ncls, _p(ws), ws.numel(), _stream(x)))
+        return dx, dw, (db if ctx.has_bias else None)
+
+
+def outconv(x, w, b):
+    """nn.ConvTranspose2d(Cin, ncls, 2, stride=2) (train/net_classification.py:56,64) on the GPU.
+    Returns NCHW-contiguous logits."""
+    return _OutConv.apply(x, w, b)
+
+
+def outconv_softmax(x, w, b):
+    """SoftMaxConv.forward without dropout (train/erfnet_blocks.py:104-110), inference only:
+    transposed convolution and softmax over the classes in one kernel."""
+    lib = _lib.lib()
+    x = _nhwc(x)
+    n, cin, h, wd = x.shape
+    ncls = w.shape[1]
+    wq, bq = _param(w), _param(b)
+    y = torch.empty((n, ncls, 2 * h, 2 * wd), dtype=torch.float32, device=x.device)
+    with _dev_ctx(x):
+        _lib.check(lib.erf_outconv_forward(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, ncls, 1,
+                                           _stream(x)))
+    return y
+
+
+# ------------------------------------------------------------------------------ plain Conv2d (1x1 / 3x3)
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        lib = _lib.lib()
+        x = _nhwc(x)
+        n, cin, h, wd = x.shape
+        cout, _, k, _ = w.shape
+        wq, bq = _param(w), _param(b)
+        y = _empty_nhwc(n, cout, h, wd, x)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_conv2d_forward(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, cout, k,
+                                              int(relu), _stream(x)))
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(x, wq, y if relu else None)
+            ctx.cfg = (k, int(relu), b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        x, wq, y = ctx.saved_tensors
+        k, relu, has_bias = ctx.cfg
+        n, cin, h, wd = x.shape
+        cout = wq.shape[0]
+        gy = _nhwc(gy)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(wq)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device)
+        ws = _workspace(x, n * h * wd, max(cin, cout))
+        with _dev_ctx(x):
+            _lib.check(lib.erf_conv2d_backward(_p(x), _p(wq), _p(y), _p(gy), _p(dx), _p(dw), _p(db), n, cin,
+                                               h, wd, cout, k, relu, _p(ws), ws.numel(), _stream(x)))
+        return dx, dw, (db if has_bias else None), None
+
+
+def conv2d(x, w, b, relu=False):
+    """nn.Conv2d with a 1x1 or 3x3 kernel, stride 1, 'same' padding (Encoder.output_conv,
+    eval/erfnet.py:85; LadderBlock.conv, train/erfnet_blocks.py:145), optionally fused with ReLU."""
+    return _Conv2d.apply(x, w, b, relu)

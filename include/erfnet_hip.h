@@ -1,0 +1,133 @@
+/*
+ * erfnet_hip.h — C ABI of liberfnet_hip.so: the ERFNet block forward/backward path as
+ * hand-written HIP kernels for gfx950 (MI355X).
+ *
+ * The reference (lorenwel/erfnet_pytorch) has no FFI: its hot path is the Python module API of
+ * train/erfnet_blocks.py, whose arithmetic runs inside torch.nn.  Each entry point below is the
+ * native replacement for one of those modules' forward()/backward pair; the reference line a
+ * function replaces is cited next to it.  The Python host side (erfnet_pytorch_amd/) binds these
+ * with ctypes and hands in raw device pointers of torch tensors plus the current HIP stream.
+ *
+ * Conventions
+ *   - All activation tensors are fp32, NHWC in memory ("channels_last" in torch terms: logical
+ *     shape [N,C,H,W], strides [H*W*C, 1, W*C, C]).  Exceptions are stated per function.
+ *   - Weights / biases / BatchNorm vectors are in torch's native layouts
+ *     (Conv2d [Cout][Cin][KH][KW], ConvTranspose2d [Cin][Cout][KH][KW]), fp32, on the device.
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous; nothing
+ *     allocates or synchronises.  Scratch memory comes from the caller (`ws`, `ws_bytes`);
+ *     query the size with erf_workspace_bytes().
+ *   - Return value 0 = launched; nonzero = rejected before any launch (bad shape, small
+ *     workspace, unsupported size); erf_last_error() then describes it.  A CPU fallback does
+ *     not exist.
+ */
+#ifndef ERFNET_HIP_H
+#define ERFNET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nn.BatchNorm2d(C, eps=1e-3) attached to a block (train/erfnet_blocks.py:23,44,50,82).
+ * mode 0: absent (use_batchnorm=False)        — all pointers may be NULL
+ * mode 1: eval, normalise with running stats
+ * mode 2: train, batch statistics; running_mean/var are updated in place (momentum, unbiased
+ *         variance); save_mean/save_invstd ([C] each) receive the batch statistics for backward.
+ * In modes 1 and 2 save_mean/save_invstd must be valid when a backward call will follow. */
+typedef struct {
+    int mode;
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    float *save_mean, *save_invstd;
+    float momentum, eps;
+} erf_bn_t;
+
+/* Library identification / diagnostics. */
+int erf_version(void);
+const char *erf_last_error(void);
+/* Number of kernel launches issued through this library by the calling process (tests use it to
+ * prove the HIP path, not a fallback, produced a result). */
+unsigned long long erf_launch_count(void);
+
+/* Upper bound of the scratch bytes any entry point needs for an activation tensor of
+ * n_pixels = N*H*W output pixels and at most max_c channels. */
+size_t erf_workspace_bytes(long long n_pixels, int max_c);
+
+/* ---- DownsamplerBlock (train/erfnet_blocks.py:15-29; eval/erfnet.py:12-23) -------------------
+ * y = relu([bn](cat([conv3x3 s2 p1 (x) -> Cout-Cin ch, maxpool2x2 s2 (x) -> Cin ch], dim=1)))
+ * x: [N,Cin,H,W] with element strides (sn,sc,sh,sw) — any layout when Cin == 3 (the network
+ *    input is read as it is), NHWC otherwise.  H and W must be even (the reference fails in
+ *    torch.cat otherwise).
+ * y: NHWC [N,Cout,H/2,W/2].  pre: NHWC buffer of the same size receiving the pre-BN
+ *    concatenation; required when bn->mode != 0 and a backward call will follow, else NULL. */
+int erf_downsampler_forward(const float *x, long long sn, long long sc, long long sh, long long sw,
+                            const float *w, const float *b, const erf_bn_t *bn, float *y,
+                            float *pre, int N, int Cin, int H, int W, int Cout, void *ws,
+                            size_t ws_bytes, void *stream);
+/* gy, y, pre: NHWC [N,Cout,H/2,W/2].  dx (NHWC [N,Cin,H,W]) may be NULL (network input).
+ * dw [Cout-Cin][Cin][3][3], db [Cout-Cin], dgamma/dbeta [Cout] (BN modes) are overwritten. */
+int erf_downsampler_backward(const float *x, long long sn, long long sc, long long sh,
+                             long long sw, const float *w, const erf_bn_t *bn, const float *y,
+                             const float *pre, const float *gy, float *dx, float *dw, float *db,
+                             float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout,
+                             void *ws, size_t ws_bytes, void *stream);
+
+/* ---- non_bottleneck_1d (train/erfnet_blocks.py:33-73; eval/erfnet.py:26-61) -----------------
+ * t1 = relu(conv3x1_1(x)); t2 = relu([bn1](conv1x3_1(t1))); t3 = relu(conv3x1_2(t2));
+ * t4 = [bn2](conv1x3_2(t3)); t4 = [dropout2d](t4); y = relu(t4 + x)
+ * "3x1" convolves along H (kernel (3,1), padding (d,0), dilation (d,1)), "1x3" along W.
+ * w[4]: conv3x1_1, conv1x3_1, conv3x1_2, conv1x3_2 weights, each [C][C][3]; b[4]: biases [C].
+ * drop_scale: NULL, or [N][C] multipliers (0 or 1/(1-p)) realising nn.Dropout2d.
+ * save: NULL for inference (two scratch tensors from ws are used), else 5 NHWC buffers of
+ *       N*C*H*W floats: t1, pre2 (pre-BN conv1x3_1 output; unused when bn1 is off), t2, t3,
+ *       pre4 (pre-BN conv1x3_2 output; unused when bn2 is off). */
+int erf_nb1d_forward(const float *x, const float *const w[4], const float *const b[4],
+                     const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil,
+                     float *y, float *const save[5], int N, int C, int H, int W, void *ws,
+                     size_t ws_bytes, void *stream);
+/* dw[4]/db[4] (and dgamma[2]/dbeta[2] in BN modes) are overwritten; dx is required. */
+int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *bn1,
+                      const erf_bn_t *bn2, const float *drop_scale, int dil, const float *y,
+                      const float *const save[5], const float *gy, float *dx, float *const dw[4],
+                      float *const db[4], float *const dgamma[2], float *const dbeta[2], int N,
+                      int C, int H, int W, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- UpsamplerBlock (train/erfnet_blocks.py:77-88; eval/erfnet.py:99-108) -------------------
+ * y = relu([bn](ConvTranspose2d(Cin,Cout,3,stride 2,padding 1,output_padding 1)(x)))
+ * x NHWC [N,Cin,H,W]; y, pre NHWC [N,Cout,2H,2W]; w [Cin][Cout][3][3]. */
+int erf_upsampler_forward(const float *x, const float *w, const float *b, const erf_bn_t *bn,
+                          float *y, float *pre, int N, int Cin, int H, int W, int Cout, void *ws,
+                          size_t ws_bytes, void *stream);
+int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, const float *y,
+                           const float *pre, const float *gy, float *dx, float *dw, float *db,
+                           float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout,
+                           void *ws, size_t ws_bytes, void *stream);
+
+/* ---- output ConvTranspose2d(Cin, ncls, 2, stride=2) (train/net_classification.py:56,64;
+ *      eval/erfnet.py:124,132; train/erfnet_blocks.py:99) --------------------------------------
+ * out[n,o,2i+a,2j+b] = bias[o] + sum_c x[n,c,i,j] * w[c,o,a,b].
+ * x NHWC [N,Cin,H,W]; y is written NCHW-contiguous [N,ncls,2H,2W] (it feeds torch's loss /
+ * argmax directly); softmax != 0 applies softmax over the class dimension
+ * (SoftMaxConv, train/erfnet_blocks.py:104-110). */
+int erf_outconv_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin,
+                        int H, int W, int ncls, int softmax, void *stream);
+/* gy NCHW [N,ncls,2H,2W] = gradient w.r.t. the conv output (pre-softmax); dx NHWC. */
+int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw,
+                         float *db, int N, int Cin, int H, int W, int ncls, void *ws,
+                         size_t ws_bytes, void *stream);
+
+/* ---- plain nn.Conv2d on NHWC tensors (Encoder.output_conv 1x1, eval/erfnet.py:85,93-94;
+ *      LadderBlock's 3x3 conv, train/erfnet_blocks.py:145,151-154) -----------------------------
+ * Square kernel k in {1,3}, stride 1, padding (k-1)/2.  relu != 0 fuses F.relu (no BN). */
+int erf_conv2d_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin,
+                       int H, int W, int Cout, int k, int relu, void *stream);
+/* gy is the gradient w.r.t. the block output; when relu != 0, y (the saved output) masks it. */
+int erf_conv2d_backward(const float *x, const float *w, const float *y, const float *gy,
+                        float *dx, float *dw, float *db, int N, int Cin, int H, int W, int Cout,
+                        int k, int relu, void *ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ERFNET_HIP_H */

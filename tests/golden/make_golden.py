@@ -172,7 +172,8 @@ def gen_blocks(manifest):
 
 
 def sd_manifest(mod):
-    return {k: list(v.shape) for k, v in mod.state_dict().items()}
+    """Ordered [key, shape] pairs: the order is part of the surface (optimizer state is indexed)."""
+    return [[k, list(v.shape)] for k, v in mod.state_dict().items()]
 
 
 def n_params(mod):
@@ -320,7 +321,7 @@ def main():
     gen_trainstep(ncl)
     gen_iou()
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
-        json.dump(manifest, f, indent=0, sort_keys=True)
+        json.dump(manifest, f, indent=0)
     for fn in sorted(os.listdir(HERE)):
         print(fn, os.path.getsize(os.path.join(HERE, fn)))
 

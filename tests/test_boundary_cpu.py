@@ -1,0 +1,153 @@
+"""CPU-side checks of the drop-in boundary: module tree / state_dict surface, the host plumbing path
+on CPU tensors against the golden vectors, and the C-ABI library's exported symbols."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+MAN = gu.load_json("manifest.json")
+NETS = gu.load_npz("nets.npz")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+MODELS = {
+    "eval_erfnet_20": ("erfnet", "ERFNet", (20,), {}),
+    "eval_erfnet_nobn_19": ("erfnet_nobn", "ERFNet", (19,), {}),
+    "net_classification_20": ("net_classification", "Net", (), dict(softmax_classes=20)),
+    "net_regression_0": ("net_regression", "Net", (), {}),
+    "net_regression_0_lik": ("net_regression", "Net", (), dict(likelihood_loss=True)),
+    "net_regression_20": ("net_regression", "Net", (), dict(softmax_classes=20)),
+    "net_regression_small_0": ("net_regression_small", "Net", (), {}),
+    "net_regression_ladder_0": ("net_regression_ladder", "Net", (), {}),
+    "net_regression_ladder_small_0": ("net_regression_ladder_small", "Net", (), {}),
+    "net_classification_ladder_20": ("net_classification_ladder", "Net", (), dict(softmax_classes=20)),
+    "imagenet_1000": ("erfnet_imagenet", "ERFNet", (1000,), {}),
+}
+
+
+def make_model(key):
+    mod, cls, args, kw = MODELS[key]
+    m = importlib.import_module("erfnet_pytorch_amd." + mod)
+    return getattr(m, cls)(*args, **kw)
+
+
+def first(o):
+    return o[0] if isinstance(o, (tuple, list)) else o
+
+
+@pytest.mark.parametrize("key", list(MODELS))
+def test_state_dict_surface(key):
+    """Same keys, same order, same shapes and parameter count as the reference's model."""
+    net = make_model(key)
+    got = [[k, list(v.shape)] for k, v in net.state_dict().items()]
+    assert got == MAN["nets"][key]["state_dict"]
+    assert sum(p.numel() for p in net.parameters()) == MAN["nets"][key]["n_params"]
+
+
+def test_upstream_alias_and_attributes():
+    from erfnet_pytorch_amd import erfnet, erfnet_imagenet, net_classification
+    assert erfnet.Net is erfnet.ERFNet
+    n = net_classification.Net(softmax_classes=20)
+    assert n.class_power.shape == (1, 20, 1, 1)
+    assert hasattr(n.encoder, "initial_block") and hasattr(n.decoder, "scalar_output_conv")
+    # hand-off used by the reference's train/main.py:857-860
+    assert hasattr(erfnet_imagenet.ERFNet(10).features, "encoder")
+
+
+@pytest.mark.parametrize("key", [k for k in MODELS if k != "imagenet_1000"])
+def test_cpu_plumbing_small(key):
+    """CPU tensors run through stock torch ops on the same parameters: logits equal the reference's."""
+    net = gu.fill_state_dict(make_model(key), tag=key).eval()
+    x = torch.from_numpy(gu.det_uniform("net.x_small", (1, 3, 64, 128), 0.0, 1.0))
+    with torch.no_grad():
+        y = first(net(x)).numpy()
+    gu.check(NETS, f"{key}/small/y", y, 1e-5, 1e-5)
+    assert np.array_equal(y.argmax(1).astype(np.uint8), NETS[f"{key}/small/argmax"])
+
+
+def test_cpu_forward_512x1024_matches_reference():
+    """BASELINE configs[0]: Net(20 classes) forward on CPU, 1x3x512x1024, vs the reference."""
+    key = "eval_erfnet_20"
+    net = gu.fill_state_dict(make_model(key), tag=key).eval()
+    x = torch.from_numpy(gu.det_uniform("net.x_big", (1, 3, 512, 1024), 0.0, 1.0))
+    with torch.no_grad():
+        y = net(x).numpy()
+    gu.check(NETS, f"{key}/big/y", y, 1e-3, 1e-3)
+    np.testing.assert_allclose(y[:, :, 224:288, 480:544], NETS[f"{key}/big/crop"], atol=1e-3)
+    assert np.array_equal(y.argmax(1).astype(np.uint8), NETS[f"{key}/big/argmax"])
+
+
+def test_only_encode_cpu():
+    key = "eval_erfnet_20"
+    net = gu.fill_state_dict(make_model(key), tag=key).eval()
+    x = torch.from_numpy(gu.det_uniform("net.x_small", (1, 3, 64, 128), 0.0, 1.0))
+    with torch.no_grad():
+        y = net(x, only_encode=True).numpy()
+    assert y.shape == (1, 20, 8, 16)
+    gu.check(NETS, "eval_erfnet_20/small/y_encode", y, 1e-5, 1e-5)
+
+
+def test_odd_size_raises_on_cpu():
+    from erfnet_pytorch_amd.erfnet_blocks import DownsamplerBlock
+    with pytest.raises(RuntimeError):
+        DownsamplerBlock(3, 16)(torch.zeros(1, 3, 15, 24))
+
+
+def test_iou_eval_golden():
+    """The reference's iouEval algorithm (eval/iouEval.py:21-75) restated with a confusion count:
+    per-class IoU = tp / (tp + fp + fn), class 19 ignored; pinned by the reference's own output."""
+    pred = gu.det_labels("iou.pred", (2, 1, 32, 48), 0, 20).reshape(-1)
+    lab = gu.det_labels("iou.lab", (2, 1, 32, 48), 0, 20).reshape(-1)
+    keep = lab != 19
+    ious = []
+    for c in range(19):
+        tp = np.sum((pred == c) & (lab == c))
+        fp = np.sum((pred == c) & (lab != c) & keep)
+        fn = np.sum((pred != c) & (lab == c))
+        ious.append(tp / (tp + fp + fn + 1e-15))
+    ref = gu.load_json("iou.json")
+    np.testing.assert_allclose(ious, ref["per_class"], rtol=1e-12)
+    assert abs(np.mean(ious) - ref["mean"]) < 1e-12
+
+
+# ------------------------------------------------------------------------------- C-ABI library
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "erfnet_hip.h")).read()
+    return sorted(set(re.findall(r"\b(erf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    """liberfnet_hip.so loads without a GPU and exports what include/erfnet_hip.h declares."""
+    from erfnet_pytorch_amd import _lib
+    so = _lib.build()
+    handle = ctypes.CDLL(so)
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(handle, name), f"{name} is declared in the header but not exported"
+    assert sorted(_lib.EXPORTS) == declared
+    handle.erf_version.restype = ctypes.c_int
+    assert handle.erf_version() >= 100
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from erfnet_pytorch_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_SO", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(RuntimeError, match="missing"):
+        _lib.lib()
+
+
+def test_product_package_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under erfnet_pytorch_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "erfnet_pytorch_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower().replace("test infrastructure", ""), f

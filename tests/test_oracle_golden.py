@@ -170,7 +170,7 @@ NETS = gu.load_npz("nets.npz")
 
 
 def _state(net):
-    return {k: gu.fill_value(k, s, tag=net) for k, s in MAN["nets"][net]["state_dict"].items()}
+    return {k: gu.fill_value(k, s, tag=net) for k, s in MAN["nets"][net]["state_dict"]}
 
 
 @pytest.mark.parametrize("net,style,bn", [("eval_erfnet_20", "eval", True),
