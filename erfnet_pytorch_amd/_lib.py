@@ -9,6 +9,11 @@ import os
 import subprocess
 import threading
 
+# torch must come first: it brings the HIP runtime (its bundled libamdhip64) that owns the tensors'
+# device memory and streams; liberfnet_hip.so then binds to that same runtime instead of pulling in
+# a second copy from /opt/rocm.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liberfnet_hip.so")
 _SRC = os.path.join(_HERE, "csrc")
@@ -96,6 +101,9 @@ def lib():
                            f"as g; g.build()'` (hipcc --offload-arch=gfx950)")
             raise RuntimeError(_load_error)
         try:
+            bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+            if os.path.exists(bundled):
+                C.CDLL(bundled, mode=C.RTLD_GLOBAL)
             handle = C.CDLL(_SO)
             for name, (res, args) in _PROTOS.items():
                 fn = getattr(handle, name)

@@ -102,8 +102,8 @@ class _Downsampler(torch.autograd.Function):
         lib = _lib.lib()
         n, cin, h, wd = x.shape
         cout = w.shape[0] + cin
-        if cin != 3:
-            x = _nhwc(x)
+        if cin != 3 or ctx.needs_input_grad[0]:
+            x = _nhwc(x)     # a 3-channel image is read through its strides unless dx is wanted
         elif x.dtype != torch.float32:
             raise TypeError("erfnet_hip kernels compute in fp32")
         need = any(ctx.needs_input_grad)
@@ -135,8 +135,6 @@ class _Downsampler(torch.autograd.Function):
         gy = _nhwc(gy)
         bn = _Bn(mode, gamma, None, None, None, momentum, eps, False, saved=(smean, sinv))
         need_dx = ctx.needs_input_grad[0]
-        if need_dx and cin == 3 and not _is_nhwc_dense(x):
-            raise RuntimeError("gradient w.r.t. a 3-channel input needs a channels_last input")
         dx = _empty_nhwc(n, cin, h, wd, x) if need_dx else None
         dw = torch.empty_like(wq)
         db = torch.empty(wq.shape[0], dtype=torch.float32, device=x.device)

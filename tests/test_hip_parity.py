@@ -1,0 +1,377 @@
+"""GPU parity tests: the HIP path (through the C ABI of liberfnet_hip.so) against
+  (1) the golden vectors generated from the reference, block by block and for whole networks,
+  (2) the plain-C CPU oracle on the same seeded inputs (with shared saved activations, which makes
+      the backward comparison strict), and
+  (3) size-independent properties at the full benchmark size.
+Tolerances: fp32, 1e-3 absolute on logits (the north-star bound); tighter where stated."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from test_boundary_cpu import MODELS, first, make_model
+
+pytestmark = pytest.mark.gpu
+
+MAN = gu.load_json("manifest.json")
+BLK = gu.load_npz("blocks.npz")
+NETS = gu.load_npz("nets.npz")
+CASES = {c["name"]: c for c in MAN["block_cases"]}
+DEV = "cuda:0"
+
+FWD_ATOL, FWD_RTOL = 2e-4, 2e-4
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def chk_fwd(case, key, arr):
+    gu.check(BLK, f"{case}/{key}", arr, FWD_ATOL, FWD_RTOL, what=f"{case}/{key}")
+
+
+def chk_grad(case, key, arr):
+    gu.check(BLK, f"{case}/{key}", arr, FWD_ATOL, FWD_RTOL, what=f"{case}/{key}", scale_rtol=3e-4,
+             outlier_frac=0.05, outlier_rtol=0.02)
+
+
+def build_block(c):
+    from erfnet_pytorch_amd import erfnet_blocks as eb
+    kind, bn = c["kind"], c["bn_mode"] > 0
+    if kind == "down":
+        return eb.DownsamplerBlock(c["cin"], c["cout"], use_batchnorm=bn)
+    if kind == "up":
+        return eb.UpsamplerBlock(c["cin"], c["cout"], use_batchnorm=bn)
+    if kind == "nb1d":
+        bn = bn and not c["name"].endswith("bn0_drop")
+        return eb.non_bottleneck_1d(c["chann"], c.get("p", 0.0), c["dilated"],
+                                    use_dropout=bool(c.get("drop_scale_key")), use_batchnorm=bn)
+    if kind == "outconv":
+        return eb.OutputConvTranspose(c["cin"], c["ncls"])
+    if kind == "softmaxconv":
+        return eb.SoftMaxConv(c["cin"], c["ncls"], 0.1, False)
+    if kind == "ladder":
+        return eb.LadderBlock(c["noutput"])
+    raise KeyError(kind)
+
+
+def launches():
+    from erfnet_pytorch_amd import _lib
+    return _lib.launch_count()
+
+
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["kind"] != "conv1x1"])
+def test_block_against_golden(name, monkeypatch):
+    c = CASES[name]
+    mod = gu.fill_state_dict(build_block(c), tag=name).to(DEV)
+    mod.train(c["bn_mode"] == 2)
+    if c.get("drop_scale_key"):
+        # inject the keep mask the fixture was generated with (nn.Dropout2d's RNG is not portable)
+        from erfnet_pytorch_amd import erfnet_blocks as eb
+        n, ch = c["inputs"][0][0], c["inputs"][0][1]
+        keep = (gu.det_uniform(c["drop_scale_key"], (n, ch, 1, 1), 0, 1) >= c["p"]).astype(np.float32)
+        scale = t(keep.reshape(n, ch) / (1.0 - c["p"]))
+        monkeypatch.setattr(eb, "_dropout2d_scale", lambda x, p, active: scale)
+        mod.train(True)
+    xs = []
+    for i, s in enumerate(c["inputs"]):
+        x = gu.det_normal(f"{name}.x{i}", tuple(s))
+        if name.endswith("relu_in"):
+            x = np.maximum(x, 0)
+        xs.append(t(x).requires_grad_(True))
+    before = launches()
+    y = mod(*xs)
+    assert launches() > before, "no HIP kernel was launched"
+    chk_fwd(name, "y", y.detach().cpu().numpy())
+    gy = t(gu.det_normal(f"{name}.gy", tuple(y.shape)))
+    y.backward(gy)
+    for i, x in enumerate(xs):
+        chk_grad(name, f"dx{i}", x.grad.cpu().numpy())
+    for k, p in mod.named_parameters():
+        if f"{name}/d:{k}" in BLK or f"{name}/d:{k}#samp" in BLK:
+            assert p.grad is not None, k
+            chk_grad(name, f"d:{k}", p.grad.cpu().numpy())
+    if c["bn_mode"] == 2:
+        for k, b in mod.named_buffers():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                chk_fwd(name, f"buf:{k}", b.cpu().numpy())
+
+
+def test_conv1x1_against_golden():
+    from erfnet_pytorch_amd import functional as hipf
+    name = "conv1x1_128_20"
+    x = t(gu.det_normal(f"{name}.x0", (2, 128, 6, 10))).requires_grad_(True)
+    w = t(gu.fill_value("weight", (20, 128, 1, 1), name)).requires_grad_(True)
+    b = t(gu.fill_value("bias", (20,), name)).requires_grad_(True)
+    y = hipf.conv2d(x, w, b)
+    chk_fwd(name, "y", y.detach().cpu().numpy())
+    y.backward(t(gu.det_normal(f"{name}.gy", tuple(y.shape))))
+    chk_grad(name, "dx0", x.grad.cpu().numpy())
+    chk_grad(name, "d:weight", w.grad.cpu().numpy())
+    chk_grad(name, "d:bias", b.grad.cpu().numpy())
+
+
+def test_downsampler_odd_size_raises():
+    from erfnet_pytorch_amd.erfnet_blocks import DownsamplerBlock
+    blk = DownsamplerBlock(16, 64).to(DEV)
+    with pytest.raises(RuntimeError):
+        blk(torch.zeros(1, 16, 15, 24, device=DEV))
+
+
+# ----------------------------------------------------------------- raw C ABI against the C oracle
+def _dptr(x):
+    return C.c_void_p(x.data_ptr())
+
+
+def _nhwc(a):
+    """numpy NCHW -> device tensor holding NHWC data."""
+    return t(np.ascontiguousarray(a.transpose(0, 2, 3, 1)))
+
+
+def _to_nchw(x, shape):
+    n, c, h, w = shape
+    return x.cpu().numpy().reshape(n, h, w, c).transpose(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("C_,dil,N,H,W", [(64, 4, 2, 20, 24), (128, 16, 1, 20, 24), (16, 1, 3, 17, 33),
+                                          (32, 2, 1, 9, 70)])
+def test_nb1d_c_abi_against_oracle(C_, dil, N, H, W):
+    """erf_nb1d_forward / erf_nb1d_backward on raw device pointers vs the oracle, the backward fed
+    with the oracle's saved activations so that both sides use identical ReLU masks."""
+    from erfnet_pytorch_amd import _lib
+    from oracle import oracle as orc
+    lib = _lib.lib()
+    tag = f"abi_nb1d_{C_}_{dil}"
+    x = np.maximum(gu.det_normal(tag + ".x", (N, C_, H, W)), 0)
+    shapes = [(C_, C_, 3, 1), (C_, C_, 1, 3), (C_, C_, 3, 1), (C_, C_, 1, 3)]
+    names = ("conv3x1_1", "conv1x3_1", "conv3x1_2", "conv1x3_2")
+    ws = [gu.fill_value(f"{n}.weight", s, tag) for n, s in zip(names, shapes)]
+    bs = [gu.fill_value(f"{n}.bias", (C_,), tag) for n in names]
+    y_ref, sv = orc.nb1d_fwd(x, ws, bs, dil, save=True)
+    gy = gu.det_normal(tag + ".gy", y_ref.shape)
+    dx_ref, dws_ref, dbs_ref, _, _ = orc.nb1d_bwd(x, ws, dil, y_ref, sv, gy)
+
+    dx_, dws, dbs = _nhwc(x), [t(w) for w in ws], [t(b) for b in bs]
+    y_ref_d, gy_d = _nhwc(y_ref), _nhwc(gy)      # keep the device copies alive across the calls
+    nel = x.size
+    y = torch.empty(nel, device=DEV)
+    save = [torch.empty(nel, device=DEV) for _ in range(5)]
+    wsb = torch.empty(int(lib.erf_workspace_bytes(N * H * W, C_)), dtype=torch.uint8, device=DEV)
+    arr = lambda ts: (C.c_void_p * len(ts))(*[x_.data_ptr() for x_ in ts])
+    _lib.check(lib.erf_nb1d_forward(_dptr(dx_), arr(dws), arr(dbs), None, None, None, dil, _dptr(y),
+                                    arr(save), N, C_, H, W, _dptr(wsb), wsb.numel(), None))
+    torch.cuda.synchronize()
+    gu.check_arrays(_to_nchw(y, x.shape), y_ref, FWD_ATOL, FWD_RTOL, what="y")
+    for got, ref, nm in ((save[0], sv[0], "t1"), (save[2], sv[2], "t2"), (save[3], sv[3], "t3")):
+        gu.check_arrays(_to_nchw(got, x.shape), ref, FWD_ATOL, FWD_RTOL, what=nm)
+
+    # backward with the oracle's activations: masks identical on both sides -> strict comparison
+    save_ref = [_nhwc(sv[0]), None, _nhwc(sv[2]), _nhwc(sv[3]), None]
+    parr = (C.c_void_p * 5)(*[None if s is None else s.data_ptr() for s in save_ref])
+    dx = torch.empty(nel, device=DEV)
+    gdw = [torch.empty(w.size, device=DEV) for w in ws]
+    gdb = [torch.empty(C_, device=DEV) for _ in range(4)]
+    none2 = (C.c_void_p * 2)(None, None)
+    _lib.check(lib.erf_nb1d_backward(_dptr(dx_), arr(dws), None, None, None, dil, _dptr(y_ref_d),
+                                     parr, _dptr(gy_d), _dptr(dx), arr(gdw), arr(gdb), none2,
+                                     none2, N, C_, H, W, _dptr(wsb), wsb.numel(), None))
+    torch.cuda.synchronize()
+    gu.check_arrays(_to_nchw(dx, x.shape), dx_ref, 5e-4, 5e-4, what="dx", scale_rtol=1e-4)
+    for i in range(4):
+        gu.check_arrays(gdw[i].cpu().numpy().reshape(ws[i].shape), dws_ref[i], 5e-4, 5e-4,
+                        what=f"dw{i}", scale_rtol=2e-4)
+        gu.check_arrays(gdb[i].cpu().numpy(), dbs_ref[i], 5e-4, 5e-4, what=f"db{i}", scale_rtol=2e-4)
+
+
+def test_c_abi_rejects_bad_arguments():
+    from erfnet_pytorch_amd import _lib
+    lib = _lib.lib()
+    x = torch.zeros(16, device=DEV)
+    # odd height: rejected before any launch, message available
+    rc = lib.erf_downsampler_forward(_dptr(x), 0, 0, 0, 0, _dptr(x), _dptr(x), None, _dptr(x), None,
+                                     1, 16, 15, 24, 64, None, 0, None)
+    assert rc != 0 and b"even" in lib.erf_last_error()
+    # workspace too small
+    rc = lib.erf_nb1d_forward(_dptr(x), (C.c_void_p * 4)(), (C.c_void_p * 4)(), None, None, None, 1,
+                              _dptr(x), None, 1, 16, 8, 8, None, 0, None)
+    assert rc != 0 and b"workspace" in lib.erf_last_error()
+
+
+# --------------------------------------------------------------------------------- whole networks
+@pytest.mark.parametrize("key", [k for k in MODELS if k != "imagenet_1000"])
+def test_whole_net_small(key):
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    x = t(gu.det_uniform("net.x_small", (1, 3, 64, 128), 0.0, 1.0))
+    with torch.no_grad():
+        y = first(net(x)).cpu().numpy()
+    gu.check(NETS, f"{key}/small/y", y, 1e-3, 1e-3)
+    if y.shape[1] > 1:
+        srt = np.sort(y, axis=1)
+        ok = (srt[:, -1] - srt[:, -2]) > 2e-3
+        assert np.array_equal(y.argmax(1).astype(np.uint8)[ok], NETS[f"{key}/small/argmax"][ok])
+
+
+def test_only_encode_gpu():
+    key = "eval_erfnet_20"
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    x = t(gu.det_uniform("net.x_small", (1, 3, 64, 128), 0.0, 1.0))
+    with torch.no_grad():
+        y = net(x, only_encode=True).cpu().numpy()
+    gu.check(NETS, "eval_erfnet_20/small/y_encode", y, 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("key", ["eval_erfnet_20", "net_classification_20"])
+def test_whole_net_512x1024_argmax(key):
+    """Cityscapes-sized input: logits within 1e-3 of the reference and identical argmax class map
+    (pixels whose top-2 margin is below the tolerance are ties and excluded)."""
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    x = t(gu.det_uniform("net.x_big", (1, 3, 512, 1024), 0.0, 1.0))
+    with torch.no_grad():
+        y = first(net(x)).cpu().numpy()
+    gu.check(NETS, f"{key}/big/y", y, 1e-3, 1e-3)
+    np.testing.assert_allclose(y[:, :, 224:288, 480:544], NETS[f"{key}/big/crop"], atol=1e-3, rtol=1e-3)
+    ok = NETS[f"{key}/big/margin"].astype(np.float32) > 2.5e-3
+    assert ok.mean() > 0.9
+    assert np.array_equal(y.argmax(1).astype(np.uint8)[ok], NETS[f"{key}/big/argmax"][ok])
+
+
+def test_imagenet_encoder():
+    key = "imagenet_1000"
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    x = t(gu.det_uniform("net.x_imagenet", (2, 3, 224, 224), 0.0, 1.0))
+    with torch.no_grad():
+        y = net(x).cpu().numpy()
+    gu.check(NETS, "imagenet_1000/y", y, 1e-3, 1e-3)
+
+
+def test_whole_net_bn_train_forward_backward():
+    """eval/erfnet.ERFNet(20) in train mode (batch statistics, dropout probability 0):
+    logits, loss, every parameter gradient and the updated running statistics."""
+    key = "eval_erfnet_20_train"
+    net = gu.fill_state_dict(make_model("eval_erfnet_20"), tag=key).to(DEV)
+    for sub in net.modules():
+        if isinstance(sub, torch.nn.Dropout2d):
+            sub.p = 0
+    net.train()
+    x = t(gu.det_uniform("net.x_train", (2, 3, 64, 128), 0.0, 1.0))
+    lab = t(gu.det_labels("net.lab_train", (2, 64, 128), -1, 20))
+    out = net(x)
+    loss = torch.nn.CrossEntropyLoss(ignore_index=-1)(out, lab)
+    loss.backward()
+    gu.check(NETS, f"{key}/y", out.detach().cpu().numpy(), 2e-3, 2e-3)
+    assert abs(loss.item() - float(NETS[f"{key}/loss"][0])) < 1e-3
+    # Gradients of this configuration (random weights, batch statistics over as few as 256 samples
+    # per channel, 23 stacked BN blocks) are ill-conditioned in fp32: the reference's own modules in
+    # fp32 differ from the same modules in fp64 by 2-3e-2 relative L2 on every parameter (measured
+    # on the GPU box with scripts/diag_bn_train.py), so that is the resolution of this check.
+    # Parameters whose gradient is analytically zero (conv biases feeding a BatchNorm) hold noise
+    # only and are skipped.  Tight whole-network gradient parity is pinned by the BN-free
+    # two-Adam-step test below.
+    checked = 0
+    for k, p in net.named_parameters():
+        name = f"{key}/d:{k}"
+        if name in NETS:
+            ref = NETS[name].astype(np.float64)
+            got = p.grad.cpu().numpy().astype(np.float64)
+        elif name + "#samp" in NETS:
+            ref = NETS[name + "#samp"].astype(np.float64)
+            flat = p.grad.cpu().numpy().reshape(-1)
+            got = flat[gu.sample_index(name, flat.size)].astype(np.float64)
+        else:
+            continue
+        if np.linalg.norm(ref) < 1e-6 * max(1.0, ref.size ** 0.5):
+            continue
+        rel = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert rel < 0.1, (k, rel)
+        checked += 1
+    assert checked > 150
+    for k, b in net.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            gu.check(NETS, f"{key}/buf:{k}", b.cpu().numpy(), 1e-4, 1e-3, what=k)
+
+
+def test_two_adam_steps_match_reference():
+    """The reference's training step (train/main.py:43-51,213,297-392): CrossEntropy(ignore -1),
+    Adam(lr 1e-4, eps 1e-4, wd 1e-6); losses and parameter checksums after two steps."""
+    ref = gu.load_json("trainstep.json")
+    net = gu.fill_state_dict(make_model("net_classification_20"), tag="trainstep").to(DEV).train()
+    opt = torch.optim.Adam(net.parameters(), 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    x = t(gu.det_uniform("trainstep.x", (2, 3, 64, 128), 0.0, 1.0))
+    lab = t(gu.det_labels("trainstep.lab", (2, 64, 128), -1, 20))
+    for step in range(2):
+        opt.zero_grad()
+        out, _ = net(x)
+        loss = crit(out, lab)
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - ref["losses"][step]) < 1e-3, (step, loss.item(), ref["losses"][step])
+    for k, p in net.named_parameters():
+        s, a = ref["params"][k]
+        pd = p.detach().double()
+        assert abs(float(pd.sum()) - s) <= 2e-4 * max(1.0, a) + 1e-5, k
+        assert abs(float(pd.abs().sum()) - a) <= 2e-4 * max(1.0, a) + 1e-5, k
+
+
+# ------------------------------------------------------------- full benchmark size: properties
+def _torch_nb1d(x, ws, bs, d):
+    import torch.nn.functional as F
+    o = F.relu(F.conv2d(x, ws[0], bs[0], padding=(1, 0)))
+    o = F.relu(F.conv2d(o, ws[1], bs[1], padding=(0, 1)))
+    o = F.relu(F.conv2d(o, ws[2], bs[2], padding=(d, 0), dilation=(d, 1)))
+    o = F.conv2d(o, ws[3], bs[3], padding=(0, d), dilation=(1, d))
+    return F.relu(o + x)
+
+
+@pytest.mark.parametrize("C_,d,H,W", [(64, 1, 128, 256), (128, 8, 64, 128), (16, 1, 256, 512)])
+def test_nb1d_full_size_vs_torch_fp32(C_, d, H, W):
+    """Batch 6 at the benchmark's stage resolutions against stock torch fp32 ops on the same device
+    (forward and all gradients; tolerance 1e-3 relative to each tensor's scale)."""
+    from erfnet_pytorch_amd import functional as hipf
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = torch.randn(6, C_, H, W, generator=g).clamp_(min=0).to(DEV)
+    shapes = [(C_, C_, 3, 1), (C_, C_, 1, 3), (C_, C_, 3, 1), (C_, C_, 1, 3)]
+    bound = (1.0 / (3 * C_)) ** 0.5
+    ws = [((torch.rand(s, generator=g) * 2 - 1) * bound * 1.7).to(DEV).requires_grad_(True) for s in shapes]
+    bs = [((torch.rand(C_, generator=g) * 2 - 1) * 0.1).to(DEV).requires_grad_(True) for _ in range(4)]
+    gy = torch.randn(6, C_, H, W, generator=g).to(DEV)
+    x1 = x.clone().requires_grad_(True)
+    y1 = hipf.nb1d(x1, ws, bs, d)
+    y1.backward(gy)
+    got = [y1.detach(), x1.grad] + [w.grad.clone() for w in ws] + [b.grad.clone() for b in bs]
+    for p in ws + bs:
+        p.grad = None
+    x2 = x.clone().requires_grad_(True)
+    y2 = _torch_nb1d(x2, ws, bs, d)
+    y2.backward(gy)
+    ref = [y2.detach(), x2.grad] + [w.grad for w in ws] + [b.grad for b in bs]
+    for i, (a, b) in enumerate(zip(got, ref)):
+        a, b = a.float().cpu().numpy(), b.float().cpu().numpy()
+        # rare ReLU mask flips (pre-activation within rounding of 0) perturb a 3x3x3-pixel
+        # neighbourhood of dx by O(|g| |w|); everything else must agree to 1e-3 of the scale
+        # (parameter gradients sum over ~50k-800k pixels, so one flip moves an element by O(1):
+        # they get a tolerance relative to the tensor's scale instead of an outlier allowance)
+        if i < 2:
+            gu.check_arrays(a, b, 1e-4, 1e-3, what=f"tensor{i}", scale_rtol=1e-3, outlier_frac=0.002,
+                            outlier_rtol=0.5)
+        else:
+            gu.check_arrays(a, b, 1e-4, 1e-3, what=f"tensor{i}", scale_rtol=5e-3)
+
+
+def test_full_size_properties_batch6():
+    """BASELINE configs[1] size (6x3x512x1024, 20 classes): run-to-run determinism, batch
+    independence (image i of the batch equals the same image alone) and finite outputs."""
+    net = gu.fill_state_dict(make_model("net_classification_20"), tag="net_classification_20").to(DEV).eval()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.rand(6, 3, 512, 1024, generator=g).to(DEV)
+    with torch.no_grad():
+        y_a = first(net(x))
+        y_b = first(net(x))
+        y_1 = first(net(x[2:3]))
+    assert y_a.shape == (6, 20, 512, 1024)
+    assert torch.isfinite(y_a).all()
+    assert torch.equal(y_a, y_b)
+    assert torch.allclose(y_a[2:3], y_1, atol=1e-5, rtol=1e-5)
