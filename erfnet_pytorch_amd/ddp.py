@@ -1,0 +1,139 @@
+"""One-process-per-GPU data parallelism for the ERFNet training step.
+
+The reference trains under single-process ``torch.nn.DataParallel`` (train/main.py:870-874): every
+step it re-broadcasts the parameters from GPU 0, scatters the batch, gathers the outputs and
+reduce-adds the gradients back onto GPU 0.  Here each rank owns one GPU and a full replica; the only
+exchange is one sum of the gradients per step, issued in a few flat buckets from autograd hooks so
+that the RCCL all-reduce of the decoder's gradients runs while the encoder is still in backward.
+
+Design points
+  * Gradients live in flat bucket buffers; each ``param.grad`` is a view into its bucket, so the
+    collective runs in place on what autograd accumulated and nothing is copied.
+  * Buckets are filled in reverse registration order (the order backward produces gradients).
+  * Parameters that never receive a gradient (the reference's unused ``bn.*`` when BatchNorm is off,
+    ``encoder.output_conv.*``, ``class_power``) are found on the first backward pass and left out of
+    later steps instead of forcing ``find_unused_parameters``.
+  * BatchNorm statistics stay per replica and dropout masks per rank, as under DataParallel.
+  * The payload is small (8.2 MB of fp32 for the 20-class network), i.e. latency-bound on xGMI:
+    few, large buckets beat many small ones.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradientReducer:
+    """Bucketed, overlapped gradient averaging for a replicated module."""
+
+    def __init__(self, module, bucket_bytes=4 << 20, process_group=None):
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self._bucket_bytes = bucket_bytes
+        self._active = None            # params known to receive gradients (after the first step)
+        self._buckets = []             # (flat buffer, [params])
+        self._pending = {}             # bucket index -> number of params still missing this step
+        self._bucket_of = {}
+        self._work = []
+        self._first_step_done = False
+        self._hooks = []
+        self._build_buckets(self.params)
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # ---------------------------------------------------------------------------------- set-up
+    def broadcast_parameters(self, src=0):
+        """Make every replica start from rank ``src``'s parameters and buffers."""
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            for t in list(self.module.parameters()) + list(self.module.buffers()):
+                dist.broadcast(t.data, src, group=self.group)
+
+    def _build_buckets(self, params):
+        self._buckets, self._bucket_of = [], {}
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= self._bucket_bytes:
+                self._finish_bucket(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._finish_bucket(cur)
+
+    def _finish_bucket(self, params):
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        off = 0
+        for p in params:
+            view = flat[off:off + p.numel()].view_as(p)
+            if p.grad is not None:
+                view.copy_(p.grad)
+            p.grad = view
+            off += p.numel()
+            self._bucket_of[p] = len(self._buckets)
+        self._buckets.append((flat, list(params)))
+
+    # ---------------------------------------------------------------------------------- per step
+    def zero_grad(self):
+        """Zero the bucket buffers (keeps ``param.grad`` bound to them)."""
+        for flat, _ in self._buckets:
+            flat.zero_()
+        self._pending = {i: len(ps) for i, (_, ps) in enumerate(self._buckets)}
+        self._work = []
+        self._seen = set()
+
+    def _on_grad(self, p):
+        if self.world == 1 and self._first_step_done:
+            return
+        b = self._bucket_of.get(p)
+        if b is None:
+            return
+        self._seen.add(p)
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and self._first_step_done:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.world == 1:
+            return
+        flat, _ = self._buckets[b]
+        self._work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+                           flat))
+        self._pending[b] = -1
+
+    def finish(self):
+        """Call after ``loss.backward()``: reduce what has not been launched, wait, average."""
+        if not self._first_step_done:
+            # first step: learn which parameters take part, then rebuild the buckets around them
+            active = [p for p in self.params if p in self._seen]
+            stale = [p for p in self.params if p not in self._seen]
+            grads = {p: p.grad.clone() for p in active}
+            for p in stale:
+                p.grad = None
+            for p in active:
+                p.grad = grads[p]
+            self._build_buckets(active)
+            self._active = active
+            self._first_step_done = True
+            self._pending = {i: 0 for i in range(len(self._buckets))}
+            for b in range(len(self._buckets)):
+                self._launch(b)
+        else:
+            for b, left in self._pending.items():
+                if left >= 0:          # bucket not launched (some parameter got no gradient this step)
+                    self._launch(b)
+        for work, flat in self._work:
+            work.wait()
+            flat.div_(self.world)
+        self._work = []
+
+    @property
+    def bucket_sizes(self):
+        return [flat.numel() * flat.element_size() for flat, _ in self._buckets]
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -303,3 +303,72 @@ def erfnet_forward(x, state, prefix_style="eval", use_bn=False, ncls=None, bn_ep
     if rc != 0:
         raise RuntimeError("H and W must be multiples of 8")
     return out
+
+
+# ------------------------------------------------------------- whole-network training pass (no BN)
+def _ce_loss_and_grad(logits, labels, ignore_index=-1):
+    """nn.CrossEntropyLoss(ignore_index=-1) (train/evaluation_functions.py:6-14): mean over the
+    labelled pixels of -log softmax; returns (loss, dloss/dlogits)."""
+    n, c, h, w = logits.shape
+    z = logits.astype(np.float64)
+    z = z - z.max(axis=1, keepdims=True)
+    lse = np.log(np.exp(z).sum(axis=1, keepdims=True))
+    logp = z - lse
+    valid = labels != ignore_index
+    cnt = max(int(valid.sum()), 1)
+    lab = np.where(valid, labels, 0)
+    picked = np.take_along_axis(logp, lab[:, None], axis=1)[:, 0]
+    loss = -(picked * valid).sum() / cnt
+    g = np.exp(logp)
+    np.put_along_axis(g, lab[:, None], np.take_along_axis(g, lab[:, None], axis=1) - 1.0, axis=1)
+    g *= (valid[:, None] / cnt)
+    return float(loss), g.astype(np.float32)
+
+
+def erfnet_train_pass(x, labels, state, prefix_style="train"):
+    """Forward + CrossEntropy + backward of the BN-free ERFNet (train/net_classification.py:41-66,
+    104-110 driven as in train/main.py:316-379), composed from the block functions above.
+    Returns (loss, {state_dict key: gradient})."""
+    x = _f(x)
+    names, _ = erfnet_param_order(prefix_style)
+    P = [_f(state[k]) for k in names]
+    plan = [("down",), ("down",)] + [("nb", 1)] * 5 + [("down",)] + \
+        [("nb", d) for _ in range(2) for d in (2, 4, 8, 16)] + \
+        [("up",), ("nb", 1), ("nb", 1), ("up",), ("nb", 1), ("nb", 1)]
+    tape, cur, pi = [], x, 0
+    for op in plan:
+        if op[0] == "nb":
+            ws, bs = P[pi:pi + 8:2], P[pi + 1:pi + 8:2]
+            y, sv = nb1d_fwd(cur, ws, bs, op[1], save=True)
+            tape.append(("nb", cur, ws, op[1], y, sv, pi))
+            pi += 8
+        elif op[0] == "down":
+            y, _ = downsampler_fwd(cur, P[pi], P[pi + 1])
+            tape.append(("down", cur, P[pi], y, pi))
+            pi += 2
+        else:
+            y, _ = upsampler_fwd(cur, P[pi], P[pi + 1])
+            tape.append(("up", cur, P[pi], y, pi))
+            pi += 2
+        cur = y
+    logits = convT2d_fwd(cur, P[pi], P[pi + 1], 2, 0, 0)
+    loss, g = _ce_loss_and_grad(logits, labels)
+    grads = {}
+    g, dw, db = convT2d_bwd(cur, P[pi], g, 2, 0, 0)
+    grads[names[pi]], grads[names[pi + 1]] = dw, db
+    for rec in reversed(tape):
+        if rec[0] == "nb":
+            _, xin, ws, d, y, sv, i = rec
+            g, dws, dbs, _, _ = nb1d_bwd(xin, ws, d, y, sv, g)
+            for j in range(4):
+                grads[names[i + 2 * j]] = dws[j].reshape(state[names[i + 2 * j]].shape)
+                grads[names[i + 2 * j + 1]] = dbs[j]
+        elif rec[0] == "down":
+            _, xin, w, y, i = rec
+            g, dw, db, _, _ = downsampler_bwd(xin, w, y, None, g, need_dx=i != 0)
+            grads[names[i]], grads[names[i + 1]] = dw, db
+        else:
+            _, xin, w, y, i = rec
+            g, dw, db, _, _ = upsampler_bwd(xin, w, y, None, g)
+            grads[names[i]], grads[names[i + 1]] = dw, db
+    return loss, grads

@@ -1,0 +1,94 @@
+"""world_size-2 gloo test of the bucketed gradient reducer (erfnet_pytorch_amd/ddp.py) on CPU:
+averaged gradients must equal the single-process gradients of the concatenated batch, unused
+parameters must be dropped after the first step, and replicas must stay identical."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _model():
+    from erfnet_pytorch_amd import net_regression_small
+    torch.manual_seed(5)
+    return net_regression_small.Net()     # 1 output channel, BatchNorm off, unused bn.* / output_conv
+
+
+def _batch(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.rand(2, 3, 32, 64, generator=g), torch.rand(2, 1, 32, 64, generator=g)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from erfnet_pytorch_amd.ddp import GradientReducer
+    model = _model()
+    if rank == 1:   # perturb: broadcast must restore rank 0's parameters
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    red = GradientReducer(model, bucket_bytes=256 << 10)
+    red.broadcast_parameters(0)
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=0.05)
+    x, y = _batch(rank)
+    snaps = []
+    for _ in range(3):
+        red.zero_grad()
+        loss = torch.nn.functional.l1_loss(model(x), y)
+        loss.backward()
+        red.finish()
+        snaps.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        opt.step()
+    torch.save({"grads": snaps, "params": {k: p.detach().clone() for k, p in model.named_parameters()},
+                "buckets": red.bucket_sizes, "n_active": len(red._active)},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_reducer_matches_single_process(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+
+    # single-process reference: same model, both ranks' batches concatenated, same SGD
+    model = _model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    xs, ys = zip(*[_batch(r) for r in range(world)])
+    x, y = torch.cat(xs), torch.cat(ys)
+    for step in range(3):
+        opt.zero_grad()
+        torch.nn.functional.l1_loss(model(x), y).backward()
+        ref = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        assert set(ref) == set(r0["grads"][step]), "set of parameters with gradients differs"
+        for k, g in ref.items():
+            torch.testing.assert_close(r0["grads"][step][k], g, rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(r1["grads"][step][k], r0["grads"][step][k], rtol=0, atol=0)
+        opt.step()
+    for k, p in model.named_parameters():
+        torch.testing.assert_close(r0["params"][k], p.detach(), rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(r1["params"][k], r0["params"][k], rtol=0, atol=0)
+    # unused parameters (bn.*, encoder.output_conv.*) are not exchanged
+    n_all = sum(1 for _ in model.parameters())
+    assert r0["n_active"] == len(ref) < n_all
+    assert len(r0["buckets"]) >= 2
