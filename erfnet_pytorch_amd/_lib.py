@@ -15,7 +15,8 @@ import threading
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liberfnet_hip.so")
+# ERFNET_HIP_SO selects another build of the same library (kernel experiments); default in-tree.
+_SO = os.environ.get("ERFNET_HIP_SO") or os.path.join(_HERE, "liberfnet_hip.so")
 _SRC = os.path.join(_HERE, "csrc")
 _lock = threading.Lock()
 _lib = None
@@ -80,7 +81,7 @@ _PROTOS = {
     "erf_outconv_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, vp, C.c_size_t, vp]),
     "erf_conv2d_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_int, vp]),
+                                     C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_conv2d_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
 }

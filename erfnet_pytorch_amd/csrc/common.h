@@ -38,11 +38,12 @@ struct Epilogue {
 //   m = (n, gi, gj) enumerates an output grid GH x GW per image;
 //   source pixel  = (gi*ss + tdh[t], gj*ss + tdw[t]) of in[N][in_H][in_W][in_C] (+in_coff), zero outside;
 //   output pixel  = (gi*os + goa[g], gj*os + gob[g]) of out[N][out_H][out_W][out_C] (+out_coff);
-//   weights       : W[t][k][j] = w[woff[t] + k*wsk + j*wsn]  (torch layouts addressed in place);
+//   weights       : W[t][k][j] = w[woff[t] + k*wsk + j*wsn] in torch's layout, repacked per call
+//                   into wp[t][k/32][j][32] (zero padded to Npad columns) by pack_weights_kernel;
 //   tap groups    : blockIdx.z = g selects taps [gtap0[g], gtap0[g]+gntaps[g]) — the output-parity
 //                   classes of a stride-2 transposed convolution; ordinary convolutions have 1 group.
 struct IgemmDesc {
-    const float *in, *w;
+    const float *in, *w, *wp;
     float *out;
     Epilogue epi;
     int N, GH, GW;
@@ -52,8 +53,9 @@ struct IgemmDesc {
     int wsk, wsn;
     int ngroups, gtap0[ERF_MAX_GROUPS], gntaps[ERF_MAX_GROUPS], goa[ERF_MAX_GROUPS], gob[ERF_MAX_GROUPS];
     int out_H, out_W, out_C, out_coff, Nout, os;
+    int Npad;          // padded column count of wp (multiple of the block's BN)
+    int cfg;           // host side: tile configuration chosen by plan_igemm
     int vec_ok;        // in_C, in_coff, K all multiples of 4 and `in` 16-byte aligned
-    int lane_along_j;  // weight gather: consecutive lanes walk j (wsn < wsk) or k
 };
 
 // Weight gradient: dW[t][k][j] = sum_m in[src(m,t)][k] * g[gpix(m,t)][j], reduced over pixels in

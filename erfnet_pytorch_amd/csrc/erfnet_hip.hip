@@ -63,49 +63,104 @@ inline int bn_mode(const erf_bn_t *bn) { return bn ? bn->mode : 0; }
 bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 // ---------------------------------------------------------------------------------- igemm launch
-int launch_igemm(IgemmDesc &d, hipStream_t st)
+// Tile configurations <WM, WN, GM, GN>: block tile BM = GM*WM*32 pixels x BN = GN*WN*32 channels.
+struct TileCfg { int bm, bn; };
+const TileCfg kCfg[] = {
+    {128, 128}, {96, 128}, {64, 128}, {32, 128},     // 0-3: Nout > 64
+    {128, 64}, {64, 64},                             // 4-5: 32 < Nout <= 64
+    {256, 32}, {128, 32},                            // 6-7: Nout <= 32
+    {128, 32},                                       // 8  : scalar-load variant
+};
+
+// Choose the tile: blocks are dealt round-robin over 256 CUs, so the kernel lasts as long as the
+// CU with the most blocks: cost = ceil(blocks / 256) * BM.  Ties go to the larger tile (fewer
+// weight-tile reloads per FLOP).
+int pick_cfg(long long M, int first, int count)
+{
+    int best = first;
+    long long best_cost = -1;
+    for (int c = first; c < first + count; ++c) {
+        const long long blocks = (M + kCfg[c].bm - 1) / kCfg[c].bm;
+        const long long cost = ((blocks + 255) / 256) * kCfg[c].bm;
+        if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+    }
+    return best;
+}
+
+// Validate, choose the tile, reserve the packed-weight buffer and describe the packing job.
+int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
 {
     if (d.K <= 0 || d.Nout <= 0) return fail("igemm: empty contraction");
     const long long M = (long long)d.N * d.GH * d.GW;
-    if (M == 0) return 0;
     if (d.in_H >= 32768 || d.in_W >= 32768 || d.GH * d.ss >= 65536 || d.GW * d.ss >= 32768)
         return fail("igemm: spatial extent too large");
     if (M * d.os * d.os >= (1LL << 31) || (long long)d.N * d.in_H * d.in_W >= (1LL << 31))
         return fail("igemm: more than 2^31 pixels");
     d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && aligned16(d.in)) ? 1 : 0;
-    d.lane_along_j = d.wsn < d.wsk ? 1 : 0;
-    dim3 grid;
-    grid.z = d.ngroups;
-    if (d.Nout > 64) {
-        constexpr int BM = 128, BN = 128;
-        grid.x = (unsigned)((M + BM - 1) / BM);
-        grid.y = (d.Nout + BN - 1) / BN;
-        igemm_f32_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(d);
-    } else if (d.Nout > 32) {
-        constexpr int BM = 256, BN = 64;
-        if (M >= 256LL * BM * 2) {
-            grid.x = (unsigned)((M + BM - 1) / BM);
-            grid.y = (d.Nout + BN - 1) / BN;
-            igemm_f32_kernel<2, 2, 4, 1><<<grid, 256, 0, st>>>(d);
-        } else {
-            grid.x = (unsigned)((M + 127) / 128);
-            grid.y = (d.Nout + BN - 1) / BN;
-            igemm_f32_kernel<1, 2, 4, 1><<<grid, 256, 0, st>>>(d);
-        }
-    } else {
-        constexpr int BN = 32;
-        if (M >= 256LL * 256 * 2) {
-            grid.x = (unsigned)((M + 255) / 256);
-            grid.y = (d.Nout + BN - 1) / BN;
-            igemm_f32_kernel<2, 1, 4, 1><<<grid, 256, 0, st>>>(d);
-        } else {
-            grid.x = (unsigned)((M + 127) / 128);
-            grid.y = (d.Nout + BN - 1) / BN;
-            igemm_f32_kernel<1, 1, 4, 1><<<grid, 256, 0, st>>>(d);
-        }
+    if (!d.vec_ok) d.cfg = 8;
+    else if (d.Nout > 64) d.cfg = pick_cfg(M, 0, 4);
+    else if (d.Nout > 32) d.cfg = pick_cfg(M, 4, 2);
+    else d.cfg = pick_cfg(M, 6, 2);
+    const int bn = kCfg[d.cfg].bn;
+    d.Npad = (d.Nout + bn - 1) / bn * bn;
+    int ntaps = 0;
+    for (int g = 0; g < d.ngroups; ++g) ntaps = d.gtap0[g] + d.gntaps[g] > ntaps ? d.gtap0[g] + d.gntaps[g] : ntaps;
+    const int kchunks = (d.K + IG_KC - 1) / IG_KC;
+    const size_t n = (size_t)ntaps * kchunks * d.Npad * IG_KC;
+    float *wp = ar.floats(n);
+    if (!wp) return fail("igemm: workspace too small for the packed weights (%zu floats)", n);
+    d.wp = wp;
+    pk.w = d.w; pk.wp = wp;
+    pk.ntaps = ntaps; pk.K = d.K; pk.Nout = d.Nout; pk.Npad = d.Npad; pk.wsk = d.wsk; pk.wsn = d.wsn;
+    for (int t = 0; t < ERF_MAX_TAPS; ++t) pk.woff[t] = d.woff[t];
+    return 0;
+}
+
+int launch_pack(const PackDesc *pks, int n, hipStream_t st)
+{
+    PackBatch b;
+    memset(&b, 0, sizeof(b));
+    size_t most = 0;
+    for (int i = 0; i < n; ++i) {
+        b.p[i] = pks[i];
+        const size_t tot = (size_t)pks[i].ntaps * ((pks[i].K + IG_KC - 1) / IG_KC) * pks[i].Npad * IG_KC;
+        most = tot > most ? tot : most;
+    }
+    dim3 grid((unsigned)((most + 255) / 256), n, 1);
+    if (grid.x > 512) grid.x = 512;
+    pack_weights_kernel<<<grid, 256, 0, st>>>(b);
+    CHECK_LAUNCH("pack_weights_kernel");
+    return 0;
+}
+
+int run_igemm(const IgemmDesc &d, hipStream_t st)
+{
+    const long long M = (long long)d.N * d.GH * d.GW;
+    if (M == 0) return 0;
+    const TileCfg c = kCfg[d.cfg];
+    dim3 grid((unsigned)((M + c.bm - 1) / c.bm), d.Npad / c.bn, d.ngroups);
+    switch (d.cfg) {
+    case 0: igemm_f32_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
+    case 1: igemm_f32_kernel<3, 1, 1, 4, true><<<grid, 256, 0, st>>>(d); break;
+    case 2: igemm_f32_kernel<2, 1, 1, 4, true><<<grid, 256, 0, st>>>(d); break;
+    case 3: igemm_f32_kernel<1, 1, 1, 4, true><<<grid, 256, 0, st>>>(d); break;
+    case 4: igemm_f32_kernel<1, 2, 4, 1, true><<<grid, 256, 0, st>>>(d); break;
+    case 5: igemm_f32_kernel<1, 1, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
+    case 6: igemm_f32_kernel<2, 1, 4, 1, true><<<grid, 256, 0, st>>>(d); break;
+    case 7: igemm_f32_kernel<1, 1, 4, 1, true><<<grid, 256, 0, st>>>(d); break;
+    default: igemm_f32_kernel<1, 1, 4, 1, false><<<grid, 256, 0, st>>>(d); break;
     }
     CHECK_LAUNCH("igemm_f32_kernel");
     return 0;
+}
+
+// Single convolution: pack its weights, then run it.
+int launch_igemm(IgemmDesc &d, Arena &ar, hipStream_t st)
+{
+    PackDesc pk;
+    if (plan_igemm(d, ar, pk)) return 1;
+    if (launch_pack(&pk, 1, st)) return 1;
+    return run_igemm(d, st);
 }
 
 // Weight gradient + slab reduction into torch's layout.  `bias_taps`: bit t set = the bias row of
@@ -118,7 +173,8 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && d.g_C % 4 == 0 &&
                 d.g_coff % 4 == 0 && d.Nout % 4 == 0 && aligned16(d.in) && aligned16(d.g)) ? 1 : 0;
     int IBLK, JBLK, cfg;
-    if (d.K > 64 && d.Nout > 64) { IBLK = 128; JBLK = 128; cfg = 0; }
+    if (!d.vec_ok) { IBLK = 32; JBLK = 32; cfg = 7; }
+    else if (d.K > 64 && d.Nout > 64) { IBLK = 128; JBLK = 128; cfg = 0; }
     else if (d.K > 64 && d.Nout > 32) { IBLK = 128; JBLK = 64; cfg = 1; }
     else if (d.K > 32 && d.Nout > 64) { IBLK = 64; JBLK = 128; cfg = 2; }
     else if (d.K > 32 && d.Nout > 32) { IBLK = 64; JBLK = 64; cfg = 3; }
@@ -129,11 +185,11 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     d.jtiles = (d.Nout + JBLK - 1) / JBLK;
     const int tiles = d.ntaps * d.itiles * d.jtiles;
     const size_t slab = (size_t)d.ntaps * d.K * d.Nout + (size_t)d.ntaps * d.Nout;
-    long long nsplit = 1536 / tiles;
+    long long nsplit = 768 / tiles;                       // about three blocks per CU
     if (nsplit < 1) nsplit = 1;
-    const long long max_by_work = (M + 127) / 128;       // at least 4 MFMA k-tiles per block
+    const long long max_by_work = (M + 255) / 256;       // at least 8 MFMA k-tiles per block
     if (nsplit > max_by_work) nsplit = max_by_work;
-    const long long max_by_mem = (long long)((48u << 20) / (slab * sizeof(float)));
+    const long long max_by_mem = (long long)((24u << 20) / (slab * sizeof(float)));
     if (nsplit > max_by_mem) nsplit = max_by_mem;
     if (nsplit < 1) nsplit = 1;
     long long sp = (M + nsplit - 1) / nsplit;
@@ -145,13 +201,14 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
     dim3 grid((unsigned)nsplit, tiles, 1);
     switch (cfg) {
-    case 0: wgrad_f32_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(d); break;
-    case 1: wgrad_f32_kernel<2, 1, 2, 2><<<grid, 256, 0, st>>>(d); break;
-    case 2: wgrad_f32_kernel<1, 2, 2, 2><<<grid, 256, 0, st>>>(d); break;
-    case 3: wgrad_f32_kernel<1, 1, 2, 2><<<grid, 256, 0, st>>>(d); break;
-    case 4: wgrad_f32_kernel<1, 1, 1, 2><<<grid, 128, 0, st>>>(d); break;
-    case 5: wgrad_f32_kernel<1, 1, 2, 1><<<grid, 128, 0, st>>>(d); break;
-    default: wgrad_f32_kernel<1, 1, 1, 1><<<grid, 64, 0, st>>>(d); break;
+    case 0: wgrad_f32_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
+    case 1: wgrad_f32_kernel<2, 1, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
+    case 2: wgrad_f32_kernel<1, 2, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
+    case 3: wgrad_f32_kernel<1, 1, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
+    case 4: wgrad_f32_kernel<1, 1, 1, 2, true><<<grid, 128, 0, st>>>(d); break;
+    case 5: wgrad_f32_kernel<1, 1, 2, 1, true><<<grid, 128, 0, st>>>(d); break;
+    case 6: wgrad_f32_kernel<1, 1, 1, 1, true><<<grid, 64, 0, st>>>(d); break;
+    default: wgrad_f32_kernel<1, 1, 1, 1, false><<<grid, 64, 0, st>>>(d); break;
     }
     CHECK_LAUNCH("wgrad_f32_kernel");
     ReduceDesc r;
@@ -160,7 +217,7 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     for (int t = 0; t < d.ntaps; ++t) r.woff[t] = woff[t];
     r.wsk = wsk; r.wsn = wsn; r.bias_taps = bias_taps;
     const long long tot = (long long)d.ntaps * d.K * d.Nout + d.Nout;
-    reduce_partials_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, st>>>(r);
+    reduce_partials_kernel<<<(unsigned)((tot + 31) / 32), 256, 0, st>>>(r);
     CHECK_LAUNCH("reduce_partials_kernel");
     return 0;
 }
@@ -373,7 +430,7 @@ int erf_downsampler_forward(const float *x, long long sn, long long sc, long lon
         d.gntaps[0] = 9;
         for (int t = 0; t < 9; ++t) { d.tdh[t] = t / 3 - 1; d.tdw[t] = t % 3 - 1; d.woff[t] = t; }
         d.wsk = 9; d.wsn = Cin * 9;
-        if (launch_igemm(d, st)) return 1;
+        if (launch_igemm(d, ar, st)) return 1;
         Epilogue pe = epi;
         pe.bias = nullptr;
         PoolDesc p = {x, dst, pe, N, H, W, Cin, Cout, Cc};
@@ -456,7 +513,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         }
         for (int t = 0; t < 9; ++t) { d.tdh[t] = pt.dh[t]; d.tdw[t] = pt.dw[t]; d.woff[t] = pt.kh[t] * 3 + pt.kw[t]; }
         d.wsk = Cin * 9; d.wsn = 9;   // W[co][ci][kh][kw]: k = co, j = ci
-        if (launch_igemm(d, st)) return 1;
+        if (launch_igemm(d, ar, st)) return 1;
     }
     return 0;
 }
@@ -486,19 +543,36 @@ int erf_nb1d_forward(const float *x, const float *const w[4], const float *const
         if (!a || !c) return fail("non_bottleneck_1d: workspace too small");
         t1 = a; p2 = c; t2 = c; t3 = a; p4 = c;
     }
-    IgemmDesc d;
+    IgemmDesc d[4];
+    PackDesc pk[4];
     // conv3x1_1 + ReLU
-    conv1d_desc(d, x, w[0], t1, N, C, H, W, 0, 1, false);
-    d.epi.bias = b[0]; d.epi.relu = 1;
-    if (launch_igemm(d, st)) return 1;
+    conv1d_desc(d[0], x, w[0], t1, N, C, H, W, 0, 1, false);
+    d[0].epi.bias = b[0]; d[0].epi.relu = 1;
     // conv1x3_1 [+ BN1] + ReLU
-    conv1d_desc(d, t1, w[1], tp1 ? p2 : t2, N, C, H, W, 1, 1, false);
-    d.epi.bias = b[1];
+    conv1d_desc(d[1], t1, w[1], tp1 ? p2 : t2, N, C, H, W, 1, 1, false);
+    d[1].epi.bias = b[1];
     if (!tp1) {
-        if (m1 == 1) d.epi.bn = bn_eval_affine(bn1);
-        d.epi.relu = 1;
+        if (m1 == 1) d[1].epi.bn = bn_eval_affine(bn1);
+        d[1].epi.relu = 1;
     }
-    if (launch_igemm(d, st)) return 1;
+    // conv3x1_2 (dilated) + ReLU
+    conv1d_desc(d[2], t2, w[2], t3, N, C, H, W, 0, dil, false);
+    d[2].epi.bias = b[2]; d[2].epi.relu = 1;
+    // conv1x3_2 (dilated) [+ BN2] [+ dropout] + residual + ReLU
+    conv1d_desc(d[3], t3, w[3], tp2 ? p4 : y, N, C, H, W, 1, dil, false);
+    d[3].epi.bias = b[3];
+    if (!tp2) {
+        if (m2 == 1) d[3].epi.bn = bn_eval_affine(bn2);
+        d[3].epi.nscale = drop_scale;
+        d[3].epi.res = x; d[3].epi.res_C = C; d[3].epi.res_coff = 0;
+        d[3].epi.relu = 1;
+    }
+    for (int i = 0; i < 4; ++i)
+        if (plan_igemm(d[i], ar, pk[i])) return 1;
+    if (launch_pack(pk, 4, st)) return 1;      // one launch repacks all four weight tensors
+
+    if (run_igemm(d[0], st)) return 1;
+    if (run_igemm(d[1], st)) return 1;
     if (tp1) {
         if (m1 == 2) { if (bn_train_stats(bn1, p2, M, C, ar, st)) return 1; }
         else if (bn_eval_prepare(bn1, C, st)) return 1;
@@ -507,20 +581,8 @@ int erf_nb1d_forward(const float *x, const float *const w[4], const float *const
         e.relu = 1;
         if (launch_elt(p2, t2, e, M, C, H * W, st)) return 1;
     }
-    // conv3x1_2 (dilated) + ReLU
-    conv1d_desc(d, t2, w[2], t3, N, C, H, W, 0, dil, false);
-    d.epi.bias = b[2]; d.epi.relu = 1;
-    if (launch_igemm(d, st)) return 1;
-    // conv1x3_2 (dilated) [+ BN2] [+ dropout] + residual + ReLU
-    conv1d_desc(d, t3, w[3], tp2 ? p4 : y, N, C, H, W, 1, dil, false);
-    d.epi.bias = b[3];
-    if (!tp2) {
-        if (m2 == 1) d.epi.bn = bn_eval_affine(bn2);
-        d.epi.nscale = drop_scale;
-        d.epi.res = x; d.epi.res_C = C; d.epi.res_coff = 0;
-        d.epi.relu = 1;
-    }
-    if (launch_igemm(d, st)) return 1;
+    if (run_igemm(d[2], st)) return 1;
+    if (run_igemm(d[3], st)) return 1;
     if (tp2) {
         if (m2 == 2) { if (bn_train_stats(bn2, p4, M, C, ar, st)) return 1; }
         else if (bn_eval_prepare(bn2, C, st)) return 1;
@@ -550,61 +612,63 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     const float *t1 = save[0], *p2 = save[1], *t2 = save[2], *t3 = save[3], *p4 = save[4];
     float *g4 = ar.floats(nel), *ga = ar.floats(nel), *gb = ar.floats(nel);
     if (!g4 || !ga || !gb) return fail("non_bottleneck_1d backward: workspace too small");
-    const size_t ws_mark = ar.off;
     const int woff[3] = {0, 1, 2};
-    IgemmDesc d;
     WgradDesc wd;
+
+    // gradient buffers of the chain: conv1x3_2 <- gin, conv3x1_2 <- gb, conv1x3_1 <- g2, conv3x1_1 <- g1
+    const float *gin = (m2 || drop_scale) ? ga : g4;
+    const float *g2 = m1 ? gb : ga;
+    float *g1 = m1 ? ga : gb;
+    IgemmDesc d[4];
+    PackDesc pk[4];
+    conv1d_desc(d[3], gin, w[3], gb, N, C, H, W, 1, dil, true);     // masked by t3 > 0
+    d[3].epi.mask = t3; d[3].epi.mask_C = C;
+    conv1d_desc(d[2], gb, w[2], ga, N, C, H, W, 0, dil, true);      // masked by t2 > 0
+    d[2].epi.mask = t2; d[2].epi.mask_C = C;
+    conv1d_desc(d[1], g2, w[1], g1, N, C, H, W, 1, 1, true);        // masked by t1 > 0
+    d[1].epi.mask = t1; d[1].epi.mask_C = C;
+    conv1d_desc(d[0], g1, w[0], dx, N, C, H, W, 0, 1, true);        // + g4 (residual path)
+    d[0].epi.res = g4; d[0].epi.res_C = C;
+    for (int i = 0; i < 4; ++i)
+        if (plan_igemm(d[i], ar, pk[i])) return 1;
+    if (launch_pack(pk, 4, st)) return 1;
+    const size_t ws_mark = ar.off;       // everything below is per-convolution scratch, reused
 
     // g4 = gy * (y > 0): gradient of the residual sum (goes to x unchanged and into the conv branch)
     if (launch_mask(gy, y, g4, M, C, st)) return 1;
-    const float *gin = g4;          // gradient w.r.t. the conv1x3_2 output
     if (m2) {
         if (bn_backward(bn2, p4, g4, nullptr, drop_scale, ga, dgamma ? dgamma[1] : nullptr,
                         dbeta ? dbeta[1] : nullptr, M, C, H * W, ar, st)) return 1;
-        gin = ga;
     } else if (drop_scale) {
         Epilogue e = kNoEpi;
         e.nscale = drop_scale;
         if (launch_elt(g4, ga, e, M, C, H * W, st)) return 1;
-        gin = ga;
     }
-    // conv1x3_2: weight gradient from (t3, gin); data gradient masked by t3 > 0
+    // conv1x3_2: weight gradient from (t3, gin); data gradient -> gb
     ar.off = ws_mark;
     wgrad1d_desc(wd, t3, gin, N, C, H, W, 1, dil);
     if (launch_wgrad(wd, dw[3], db[3], woff, 3, C * 3, 1u, ar, st)) return 1;
-    conv1d_desc(d, gin, w[3], gb, N, C, H, W, 1, dil, true);
-    d.epi.mask = t3; d.epi.mask_C = C;
-    if (launch_igemm(d, st)) return 1;
-    // conv3x1_2: (t2, gb) -> ga masked by t2 > 0
+    if (run_igemm(d[3], st)) return 1;
+    // conv3x1_2: (t2, gb) -> ga
     ar.off = ws_mark;
     wgrad1d_desc(wd, t2, gb, N, C, H, W, 0, dil);
     if (launch_wgrad(wd, dw[2], db[2], woff, 3, C * 3, 1u, ar, st)) return 1;
-    conv1d_desc(d, gb, w[2], ga, N, C, H, W, 0, dil, true);
-    d.epi.mask = t2; d.epi.mask_C = C;
-    if (launch_igemm(d, st)) return 1;
-    const float *g2 = ga;
-    float *g1 = gb;
+    if (run_igemm(d[2], st)) return 1;
     if (m1) {
         ar.off = ws_mark;
         if (bn_backward(bn1, p2, ga, nullptr, nullptr, gb, dgamma ? dgamma[0] : nullptr,
                         dbeta ? dbeta[0] : nullptr, M, C, H * W, ar, st)) return 1;
-        g2 = gb;
-        g1 = ga;
     }
-    // conv1x3_1: (t1, g2) -> g1 masked by t1 > 0
+    // conv1x3_1: (t1, g2) -> g1
     ar.off = ws_mark;
     wgrad1d_desc(wd, t1, g2, N, C, H, W, 1, 1);
     if (launch_wgrad(wd, dw[1], db[1], woff, 3, C * 3, 1u, ar, st)) return 1;
-    conv1d_desc(d, g2, w[1], g1, N, C, H, W, 1, 1, true);
-    d.epi.mask = t1; d.epi.mask_C = C;
-    if (launch_igemm(d, st)) return 1;
+    if (run_igemm(d[1], st)) return 1;
     // conv3x1_1: (x, g1) -> dx = dgrad + g4
     ar.off = ws_mark;
     wgrad1d_desc(wd, x, g1, N, C, H, W, 0, 1);
     if (launch_wgrad(wd, dw[0], db[0], woff, 3, C * 3, 1u, ar, st)) return 1;
-    conv1d_desc(d, g1, w[0], dx, N, C, H, W, 0, 1, true);
-    d.epi.res = g4; d.epi.res_C = C;
-    if (launch_igemm(d, st)) return 1;
+    if (run_igemm(d[0], st)) return 1;
     return 0;
 }
 
@@ -640,7 +704,7 @@ int erf_upsampler_forward(const float *x, const float *w, const float *b, const 
     }
     for (int t = 0; t < 9; ++t) { d.tdh[t] = pt.dh[t]; d.tdw[t] = pt.dw[t]; d.woff[t] = pt.kh[t] * 3 + pt.kw[t]; }
     d.wsk = Cout * 9; d.wsn = 9;       // W[ci][co][kh][kw]: k = ci, j = co
-    if (launch_igemm(d, st)) return 1;
+    if (launch_igemm(d, ar, st)) return 1;
     if (two_pass) {
         if (mode == 2) { if (bn_train_stats(bn, dst, Mo, Cout, ar, st)) return 1; }
         else if (bn_eval_prepare(bn, Cout, st)) return 1;
@@ -693,7 +757,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
         d.gntaps[0] = 9;
         for (int t = 0; t < 9; ++t) { d.tdh[t] = t / 3 - 1; d.tdw[t] = t % 3 - 1; d.woff[t] = t; }
         d.wsk = 9; d.wsn = Cout * 9;   // W[ci][co][kh][kw]: k = co, j = ci
-        if (launch_igemm(d, st)) return 1;
+        if (launch_igemm(d, ar, st)) return 1;
     }
     return 0;
 }
@@ -755,9 +819,10 @@ static void conv2d_taps(int k, int *dh, int *dw, int *woff, bool transpose)
 }
 
 int erf_conv2d_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin, int H,
-                       int W, int Cout, int k, int relu, void *stream)
+                       int W, int Cout, int k, int relu, void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
     if (k != 1 && k != 3) return fail("conv2d: kernel size must be 1 or 3");
     IgemmDesc d;
     zero_desc(d);
@@ -769,7 +834,7 @@ int erf_conv2d_forward(const float *x, const float *w, const float *b, float *y,
     d.gntaps[0] = k * k;
     conv2d_taps(k, d.tdh, d.tdw, d.woff, false);
     d.wsk = k * k; d.wsn = Cin * k * k;
-    return launch_igemm(d, st);
+    return launch_igemm(d, ar, st);
 }
 
 int erf_conv2d_backward(const float *x, const float *w, const float *y, const float *gy, float *dx,
@@ -807,7 +872,7 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
         d.gntaps[0] = k * k;
         conv2d_taps(k, d.tdh, d.tdw, d.woff, true);
         d.wsk = Cin * k * k; d.wsn = k * k;
-        if (launch_igemm(d, st)) return 1;
+        if (launch_igemm(d, ar, st)) return 1;
     }
     return 0;
 }

@@ -24,6 +24,38 @@
 #define IG_KC 32          // channels per K-step
 #define IG_BPITCH 36      // floats per B-tile row (k) : 144 B keeps 16-B alignment, spreads banks
 
+// Weights are repacked once per call from torch's layout into the order the B tile is consumed:
+//   wp[tap][k-chunk][j][32]  (k = contraction channel, j = output channel, zero padded to Npad
+//   columns and to whole 32-channel chunks), so a K-step's B tile is one contiguous run that is
+//   copied with 16-byte loads.  Up to four convolutions (one non_bottleneck_1d) per launch.
+struct PackDesc {
+    const float *w;
+    float *wp;
+    int ntaps, K, Nout, Npad, wsk, wsn;
+    int woff[ERF_MAX_TAPS];
+};
+struct PackBatch {
+    PackDesc p[4];
+};
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackBatch b)
+{
+    const PackDesc &d = b.p[blockIdx.y];
+    const int kchunks = (d.K + IG_KC - 1) / IG_KC;
+    const int total = d.ntaps * kchunks * d.Npad * IG_KC;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int kk = idx % IG_KC;
+        int r = idx / IG_KC;
+        const int j = r % d.Npad;
+        r /= d.Npad;
+        const int kc = r % kchunks, t = r / kchunks;
+        const int k = kc * IG_KC + kk;
+        float v = 0.0f;
+        if (k < d.K && j < d.Nout) v = d.w[d.woff[t] + (long long)k * d.wsk + (long long)j * d.wsn];
+        d.wp[idx] = v;
+    }
+}
+
 struct RowInfo {          // per output pixel of the block tile
     int src_base;         // n * in_H * in_W   (pixel index), -1 = row beyond M
     int hs_ws;            // (gi*ss) | (gj*ss) << 16
@@ -31,17 +63,26 @@ struct RowInfo {          // per output pixel of the block tile
     int n;
 };
 
-template <int WM, int WN, int GM, int GN>
+// Main loop: LDS double buffering with one barrier per K-step.  In step s a wave first writes the
+// tile of step s+1 (loaded into registers during step s-1) into the buffer that was read in step
+// s-1, issues the global loads of step s+2, and then runs the MFMAs of step s from the other buffer.
+template <int WM, int WN, int GM, int GN, bool VEC>
 __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDesc d)
 {
     constexpr int BM = GM * WM * 32, BN = GN * WN * 32, NT = GM * GN * 64;
-    constexpr int A_PASSES = BM / (NT / 8);      // float4 loads per thread per step
-    constexpr int B_ELEMS = BN * IG_KC / NT;     // scalar weight loads per thread per step
-    __shared__ __attribute__((aligned(16))) float As[BM * IG_KC];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * IG_BPITCH];
+    constexpr int A_SLOTS = BM * 8, B_SLOTS = BN * 8;            // float4 slots per tile
+    constexpr int A_PASSES = (A_SLOTS + NT - 1) / NT, B_PASSES = (B_SLOTS + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * IG_KC];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * IG_BPITCH];
     __shared__ RowInfo rows[BM];
+    __shared__ int taps[ERF_MAX_TAPS * 2];   // {dh, dw} per tap, read with ds_read: keeps the tap
+                                             // lookup off the vector-memory counter
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < ERF_MAX_TAPS) {
+        taps[tid * 2 + 0] = d.tdh[tid];
+        taps[tid * 2 + 1] = d.tdw[tid];
+    }
     const int wm = wave / GN, wn = wave % GN;
     const int l31 = lane & 31, h = lane >> 5;
     const int grp = blockIdx.z;
@@ -79,68 +120,78 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    f32x4 areg[A_PASSES];
-    float breg[B_ELEMS];
-    const int ac = tid & 7;          // 16-byte chunk of the 128-B channel row
-    const int ar = tid >> 3;         // first row handled by this thread
-    // Weight gather: element i of this thread is (k, j) = (bk0 + i*bdk, bj0 + i*bdj); consecutive
-    // lanes walk whichever of k / j has the smaller stride in torch's weight layout.
-    static_assert(NT % IG_KC == 0 && NT % BN == 0, "weight gather tiling");
-    int bk0, bj0, bdk, bdj;
-    if (d.lane_along_j) { bj0 = tid % BN; bk0 = tid / BN; bdk = NT / BN; bdj = 0; }
-    else { bk0 = tid % IG_KC; bj0 = tid / IG_KC; bdk = 0; bdj = NT / IG_KC; }
-    const long long bstep = (long long)bdk * d.wsk + (long long)bdj * d.wsn;
-    const long long bbase = (long long)bk0 * d.wsk + (long long)(j0 + bj0) * d.wsn;
-    const int blds0 = bj0 * IG_BPITCH + bk0, bldsd = bdj * IG_BPITCH + bdk;
+    f32x4 areg[A_PASSES], breg[B_PASSES];
+    unsigned amask = 0;              // bit i: pass i holds real data (else it is stored as zero)
 
     auto load_step = [&](int s) {
         const int t = tap0 + s / kchunks;
-        const int kc0 = (s % kchunks) * IG_KC;
-        const int dh = d.tdh[t], dw = d.tdw[t];
+        const int kc = s % kchunks, kc0 = kc * IG_KC;
+        const int dh = taps[t * 2 + 0], dw = taps[t * 2 + 1];
+        // Every load is issued unconditionally (an out-of-image tap or a padded channel reads a
+        // valid dummy address; the value is replaced by zero when it is written to LDS): a branch
+        // around a load, or a select right behind it, makes the compiler wait for each load
+        // separately and serialises their latencies.
+        unsigned am = 0;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
-            const RowInfo ri = rows[ar + i * (NT / 8)];
+            const int slot = tid + i * NT;
+            const int r = slot >> 3, ac = slot & 7;
+            const RowInfo ri = rows[r < BM ? r : 0];
             const int ih = (ri.hs_ws & 0xffff) + dh, iw = (ri.hs_ws >> 16) + dw;
             const int kk = kc0 + ac * 4;
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (ri.src_base >= 0 && (unsigned)ih < (unsigned)d.in_H && (unsigned)iw < (unsigned)d.in_W &&
-                kk < d.K) {
-                const float *p = d.in + ((long long)(ri.src_base + ih * d.in_W + iw) * d.in_C + d.in_coff + kk);
-                if (d.vec_ok) {
-                    v = *reinterpret_cast<const f32x4 *>(p);
-                } else {
+            const bool ok = slot < A_SLOTS && ri.src_base >= 0 && (unsigned)ih < (unsigned)d.in_H &&
+                            (unsigned)iw < (unsigned)d.in_W && kk < d.K;
+            const long long off = ok ? ((long long)(ri.src_base + ih * d.in_W + iw) * d.in_C + d.in_coff + kk) : 0;
+            const float *p = d.in + off;
+            f32x4 v;
+            if (VEC) {
+                v = *reinterpret_cast<const f32x4 *>(p);
+            } else {        // channel counts / alignment that rule out 16-byte loads (rare)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (kk + e < d.K) v[e] = p[e];
-                }
+                for (int e = 0; e < 4; ++e) v[e] = (ok && kk + e < d.K) ? p[e] : 0.0f;
             }
             areg[i] = v;
+            am |= (ok ? 1u : 0u) << i;
         }
-        const float *wt = d.w + d.woff[t] + (long long)kc0 * d.wsk + bbase;
+        amask = am;
+        const float *wt = d.wp + ((long long)(t * kchunks + kc) * d.Npad + j0) * IG_KC;
 #pragma unroll
-        for (int i = 0; i < B_ELEMS; ++i) {
-            float v = 0.0f;
-            if (kc0 + bk0 + i * bdk < d.K && j0 + bj0 + i * bdj < d.Nout) v = wt[i * bstep];
-            breg[i] = v;
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int slot = tid + i * NT;
+            breg[i] = *reinterpret_cast<const f32x4 *>(wt + (slot < B_SLOTS ? slot : 0) * 4);
         }
     };
 
-    auto store_step = [&]() {
+    auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
-            const int r = ar + i * (NT / 8);
-            *reinterpret_cast<f32x4 *>(&As[r * IG_KC + ((ac ^ ((r >> 1) & 7)) << 2)]) = areg[i];
+            const int slot = tid + i * NT;
+            const int r = slot >> 3, ac = slot & 7;
+            f32x4 v = areg[i];
+            if (!((amask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (A_SLOTS % NT == 0 || slot < A_SLOTS)
+                *reinterpret_cast<f32x4 *>(&As[buf][r * IG_KC + ((ac ^ ((r >> 1) & 7)) << 2)]) = v;
         }
 #pragma unroll
-        for (int i = 0; i < B_ELEMS; ++i) Bs[blds0 + i * bldsd] = breg[i];
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int slot = tid + i * NT;
+            if (B_SLOTS % NT == 0 || slot < B_SLOTS)
+                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot >> 3) * IG_BPITCH + (slot & 7) * 4]) = breg[i];
+        }
     };
 
     load_step(0);
+    store_step(0);
+    if (nsteps > 1) load_step(1);
+    __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
-        store_step();
-        __syncthreads();
-        if (s + 1 < nsteps) load_step(s + 1);
+        const int buf = s & 1;
+        if (s + 1 < nsteps) {
+            store_step(buf ^ 1);
+            if (s + 2 < nsteps) load_step(s + 2);
+        }
         const int kc0 = (s % kchunks) * IG_KC;
+        const float *Ab = As[buf], *Bb = Bs[buf];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (kc0 + q * 8 >= d.K) break;     // wave-uniform: short last chunk (K = 16)
@@ -148,12 +199,12 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
 #pragma unroll
             for (int a = 0; a < WM; ++a) {
                 const int row = (wm * WM + a) * 32 + l31;
-                af[a] = *reinterpret_cast<const f32x4 *>(&As[row * IG_KC + (((2 * q + h) ^ ((row >> 1) & 7)) << 2)]);
+                af[a] = *reinterpret_cast<const f32x4 *>(&Ab[row * IG_KC + (((2 * q + h) ^ ((row >> 1) & 7)) << 2)]);
             }
 #pragma unroll
             for (int b = 0; b < WN; ++b) {
                 const int col = (wn * WN + b) * 32 + l31;
-                bf[b] = *reinterpret_cast<const f32x4 *>(&Bs[col * IG_BPITCH + q * 8 + h * 4]);
+                bf[b] = *reinterpret_cast<const f32x4 *>(&Bb[col * IG_BPITCH + q * 8 + h * 4]);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
@@ -175,14 +226,30 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
         epi_channel_affine(d.epi, c, sc, sh);
 #pragma unroll
         for (int a = 0; a < WM; ++a) {
+            // gather the epilogue operands of all 16 rows first (unconditional loads), then store
+            int opix[16], on[16];
+            float rres[16], rmask[16], rns[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const RowInfo ri = rows[row];
-                if (ri.out_pix < 0) continue;
+                opix[r] = ri.out_pix;
+                on[r] = ri.n;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long px = opix[r] < 0 ? 0 : opix[r];
+                rres[r] = d.epi.res ? d.epi.res[px * d.epi.res_C + d.epi.res_coff + c] : 0.0f;
+                rmask[r] = d.epi.mask ? d.epi.mask[px * d.epi.mask_C + d.epi.mask_coff + c] : 1.0f;
+                rns[r] = d.epi.nscale ? d.epi.nscale[(long long)on[r] * d.Nout + c] : 1.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float v = acc[a][b][r] * sc + sh;
-                v = epi_finish(d.epi, v, ri.out_pix, ri.n, c, d.Nout);
-                d.out[(long long)ri.out_pix * d.out_C + d.out_coff + c] = v;
+                v = v * rns[r] + rres[r];
+                if (d.epi.relu) v = fmaxf(v, 0.0f);
+                v = rmask[r] > 0.0f ? v : 0.0f;
+                if (opix[r] >= 0) d.out[(long long)opix[r] * d.out_C + d.out_coff + c] = v;
             }
         }
     }
@@ -193,7 +260,7 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
 // one tap; blockIdx.x = pixel slab, blockIdx.y = (tap, i-tile, j-tile).
 // LDS: X tile [32 pixels][IBLK], G tile [32 pixels][JBLK]; MFMA operands are read with ds_read_b32
 // (lanes walk the channel, the two lane halves take pixel 2s and 2s+1).
-template <int IB, int JB, int GI, int GJ>
+template <int IB, int JB, int GI, int GJ, bool VEC>
 __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc d)
 {
     constexpr int IBLK = GI * IB * 32, JBLK = GJ * JB * 32, NT = GI * GJ * 64;
@@ -214,9 +281,10 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
     const int i0 = it * IBLK, j0 = jt * JBLK;
     const int dh = d.tdh[t], dw = d.tdw[t], oa = d.toa[t], ob = d.tob[t];
 
-    const long long M = (long long)d.N * d.GH * d.GW;
-    const long long mbeg = (long long)blockIdx.x * d.split_pixels;
-    long long mend = mbeg + d.split_pixels;
+    // pixel indices fit 31 bits (checked on the host): 32-bit index arithmetic throughout
+    const unsigned M = (unsigned)d.N * d.GH * d.GW, GHW = (unsigned)d.GH * d.GW;
+    const unsigned mbeg = blockIdx.x * (unsigned)d.split_pixels;
+    unsigned mend = mbeg + d.split_pixels;
     if (mend > M) mend = M;
     const int nsteps = mbeg < mend ? (int)((mend - mbeg + PM - 1) / PM) : 0;
 
@@ -232,67 +300,72 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
     for (int b = 0; b < JB; ++b) bsum[b] = 0.0f;
 
     f32x4 xreg[XP], greg[GP];
+    unsigned xmask = 0, gmask = 0;
 
     auto load_step = [&](int s) {
-        const long long mb = mbeg + (long long)s * PM;
+        const unsigned mb = mbeg + (unsigned)s * PM;
+        // unconditional loads with a dummy address for masked slots, zeroed at the LDS store
+        // (see igemm_f32_kernel)
+        unsigned xm = 0, gm = 0;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int slot = tid + i * NT;
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (slot < XV) {
-                const int p = slot / (IBLK / 4), c = (slot % (IBLK / 4)) * 4;
-                const long long m = mb + p;
-                if (m < mend && i0 + c < d.K) {
-                    const int n = (int)(m / (d.GH * d.GW));
-                    const int rem = (int)(m - (long long)n * d.GH * d.GW);
-                    const int gi = rem / d.GW, gj = rem - gi * d.GW;
-                    const int ih = gi * d.ss + dh, iw = gj * d.ss + dw;
-                    if ((unsigned)ih < (unsigned)d.in_H && (unsigned)iw < (unsigned)d.in_W) {
-                        const float *px = d.in + (((long long)n * d.in_H + ih) * d.in_W + iw) * d.in_C + d.in_coff + i0 + c;
-                        if (d.vec_ok) v = *reinterpret_cast<const f32x4 *>(px);
-                        else {
+            const int p = slot / (IBLK / 4), c = (slot % (IBLK / 4)) * 4;
+            const unsigned m = mb + p;
+            bool ok = slot < XV && m < mend && i0 + c < d.K;
+            const unsigned mm = ok ? m : mbeg;
+            const unsigned n = mm / GHW, rem = mm - n * GHW;
+            const unsigned gi = rem / (unsigned)d.GW, gj = rem - gi * d.GW;
+            const int ih = (int)gi * d.ss + dh, iw = (int)gj * d.ss + dw;
+            ok = ok && (unsigned)ih < (unsigned)d.in_H && (unsigned)iw < (unsigned)d.in_W;
+            const long long off = ok ? ((long long)((n * d.in_H + ih) * d.in_W + iw) * d.in_C + d.in_coff + i0 + c) : 0;
+            const float *px = d.in + off;
+            f32x4 v;
+            if (VEC) v = *reinterpret_cast<const f32x4 *>(px);
+            else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (i0 + c + e < d.K) v[e] = px[e];
-                        }
-                    }
-                }
+                for (int e = 0; e < 4; ++e) v[e] = (ok && i0 + c + e < d.K) ? px[e] : 0.0f;
             }
             xreg[i] = v;
+            xm |= (ok ? 1u : 0u) << i;
         }
+        xmask = xm;
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
             const int slot = tid + i * NT;
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (slot < GV) {
-                const int p = slot / (JBLK / 4), c = (slot % (JBLK / 4)) * 4;
-                const long long m = mb + p;
-                if (m < mend && j0 + c < d.Nout) {
-                    const int n = (int)(m / (d.GH * d.GW));
-                    const int rem = (int)(m - (long long)n * d.GH * d.GW);
-                    const int gi = rem / d.GW, gj = rem - gi * d.GW;
-                    const float *pg = d.g + (((long long)n * d.g_H + gi * d.os + oa) * d.g_W + gj * d.os + ob) * d.g_C + d.g_coff + j0 + c;
-                    if (d.vec_ok) v = *reinterpret_cast<const f32x4 *>(pg);
-                    else {
+            const int p = slot / (JBLK / 4), c = (slot % (JBLK / 4)) * 4;
+            const unsigned m = mb + p;
+            const bool ok = slot < GV && m < mend && j0 + c < d.Nout;
+            const unsigned mm = ok ? m : mbeg;
+            const unsigned n = mm / GHW, rem = mm - n * GHW;
+            const unsigned gi = rem / (unsigned)d.GW, gj = rem - gi * d.GW;
+            const long long off = ok ? ((long long)((n * d.g_H + gi * d.os + oa) * d.g_W + gj * d.os + ob) * d.g_C + d.g_coff + j0 + c) : 0;
+            const float *pg = d.g + off;
+            f32x4 v;
+            if (VEC) v = *reinterpret_cast<const f32x4 *>(pg);
+            else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (j0 + c + e < d.Nout) v[e] = pg[e];
-                    }
-                }
+                for (int e = 0; e < 4; ++e) v[e] = (ok && j0 + c + e < d.Nout) ? pg[e] : 0.0f;
             }
             greg[i] = v;
+            gm |= (ok ? 1u : 0u) << i;
         }
+        gmask = gm;
     };
     auto store_step = [&]() {
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int slot = tid + i * NT;
-            if (slot < XV) *reinterpret_cast<f32x4 *>(&Xs[slot * 4]) = xreg[i];
+            f32x4 v = xreg[i];
+            if (!((xmask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (slot < XV) *reinterpret_cast<f32x4 *>(&Xs[slot * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
             const int slot = tid + i * NT;
-            if (slot < GV) *reinterpret_cast<f32x4 *>(&Gs[slot * 4]) = greg[i];
+            f32x4 v = greg[i];
+            if (!((gmask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (slot < GV) *reinterpret_cast<f32x4 *>(&Gs[slot * 4]) = v;
         }
     };
 
@@ -354,25 +427,37 @@ struct ReduceDesc {
     unsigned bias_taps;
 };
 
+// Block = 32 consecutive slab elements x 8 slab groups: thread (g, e) sums slabs g, g+8, ... of
+// element e, the 8 group sums are then added in a fixed order through LDS.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceDesc d)
 {
+    __shared__ float red[8][33];
     const long long nw = (long long)d.ntaps * d.K * d.Nout;
     const long long slab = nw + (long long)d.ntaps * d.Nout;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nw + d.Nout) return;
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const long long idx = (long long)blockIdx.x * 32 + e;
     float s = 0.0f;
     if (idx < nw) {
-        for (int i = 0; i < d.nsplit; ++i) s += d.partial[(long long)i * slab + idx];
-        const int j = (int)(idx % d.Nout);
-        const int k = (int)((idx / d.Nout) % d.K);
-        const int t = (int)(idx / ((long long)d.Nout * d.K));
-        d.dw[d.woff[t] + (long long)k * d.wsk + (long long)j * d.wsn] = s;
-    } else if (d.db) {
+        for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + idx];
+    } else if (idx < nw + d.Nout) {
         const int j = (int)(idx - nw);
         for (int t = 0; t < d.ntaps; ++t) {
             if (!((d.bias_taps >> t) & 1u)) continue;
-            for (int i = 0; i < d.nsplit; ++i) s += d.partial[(long long)i * slab + nw + (long long)t * d.Nout + j];
+            for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + nw + (long long)t * d.Nout + j];
         }
-        d.db[j] = s;
+    }
+    red[g][e] = s;
+    __syncthreads();
+    if (g != 0 || idx >= nw + d.Nout) return;
+    float tot = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) tot += red[k][e];
+    if (idx < nw) {
+        const int j = (int)(idx % d.Nout);
+        const int k = (int)((idx / d.Nout) % d.K);
+        const int t = (int)(idx / ((long long)d.Nout * d.K));
+        d.dw[d.woff[t] + (long long)k * d.wsk + (long long)j * d.wsn] = tot;
+    } else if (d.db) {
+        d.db[idx - nw] = tot;
     }
 }

@@ -352,9 +352,10 @@ class _Conv2d(torch.autograd.Function):
         cout, _, k, _ = w.shape
         wq, bq = _param(w), _param(b)
         y = _empty_nhwc(n, cout, h, wd, x)
+        ws = _workspace(x, n * h * wd, max(cin, cout))
         with _dev_ctx(x):
             _lib.check(lib.erf_conv2d_forward(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, cout, k,
-                                              int(relu), _stream(x)))
+                                              int(relu), _p(ws), ws.numel(), _stream(x)))
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, wq, y if relu else None)
             ctx.cfg = (k, int(relu), b is not None)

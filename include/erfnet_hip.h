@@ -121,7 +121,8 @@ int erf_outconv_backward(const float *x, const float *w, const float *gy, float 
  *      LadderBlock's 3x3 conv, train/erfnet_blocks.py:145,151-154) -----------------------------
  * Square kernel k in {1,3}, stride 1, padding (k-1)/2.  relu != 0 fuses F.relu (no BN). */
 int erf_conv2d_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin,
-                       int H, int W, int Cout, int k, int relu, void *stream);
+                       int H, int W, int Cout, int k, int relu, void *ws, size_t ws_bytes,
+                       void *stream);
 /* gy is the gradient w.r.t. the block output; when relu != 0, y (the saved output) masks it. */
 int erf_conv2d_backward(const float *x, const float *w, const float *y, const float *gy,
                         float *dx, float *dw, float *db, int N, int Cin, int H, int W, int Cout,
