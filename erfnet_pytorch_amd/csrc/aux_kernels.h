@@ -136,16 +136,25 @@ __global__ __launch_bounds__(512) void first_down_wgrad_kernel(const FirstDownWg
     }
 }
 
-// out[i] = sum_s partial[s][i]
+// out[i] = sum_s partial[s][i].  Block = 32 elements x 8 slab groups; the 8 group sums are added in
+// a fixed order through LDS (bitwise reproducible).
 __global__ __launch_bounds__(256) void reduce_flat_kernel(const float *partial, float *dw, float *db,
                                                           int nsplit, int nw, int nb)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nw + nb) return;
+    __shared__ float red[8][33];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
     float s = 0.0f;
-    for (int i = 0; i < nsplit; ++i) s += partial[(long long)i * (nw + nb) + idx];
-    if (idx < nw) dw[idx] = s;
-    else if (db) db[idx - nw] = s;
+    if (idx < nw + nb)
+        for (int i = g; i < nsplit; i += 8) s += partial[(long long)i * (nw + nb) + idx];
+    red[g][e] = s;
+    __syncthreads();
+    if (g != 0 || idx >= nw + nb) return;
+    float tot = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) tot += red[k][e];
+    if (idx < nw) dw[idx] = tot;
+    else if (db) db[idx - nw] = tot;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -579,22 +588,33 @@ __global__ __launch_bounds__(512) void outconv_wgrad_kernel(const OutConvBwdDesc
     }
 }
 
-// dw[c][o][a][b] = sum_s P[s][oab][c];  db[o] = sum_s sum_ab P[s][bias][o*4+ab]
+// dw[c][o][a][b] = sum_s P[s][oab][c];  db[o] = sum_s sum_ab P[s][bias][o*4+ab].
+// Block = 32 slab elements x 8 slab groups, fixed summation order.
 __global__ __launch_bounds__(256) void outconv_wreduce_kernel(const float *partial, float *dw, float *db,
                                                               int nsplit, int ncls)
 {
-    const int nab = ncls * 4, slab = nab * OC_CIN + nab;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx < nab * OC_CIN) {
-        float s = 0.0f;
-        for (int i = 0; i < nsplit; ++i) s += partial[(long long)i * slab + idx];
+    __shared__ float red[8][33];
+    const int nab = ncls * 4, nw = nab * OC_CIN, slab = nw + nab;
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
+    float s = 0.0f;
+    if (idx < nw) {
+        for (int i = g; i < nsplit; i += 8) s += partial[(long long)i * slab + idx];
+    } else if (idx < nw + ncls) {
+        const int o = idx - nw;
+        for (int i = g; i < nsplit; i += 8)
+            for (int ab = 0; ab < 4; ++ab) s += partial[(long long)i * slab + nw + o * 4 + ab];
+    }
+    red[g][e] = s;
+    __syncthreads();
+    if (g != 0 || idx >= nw + ncls) return;
+    float tot = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) tot += red[k][e];
+    if (idx < nw) {
         const int c = idx % OC_CIN, oab = idx / OC_CIN;
-        dw[c * nab + oab] = s;
-    } else if (idx < nab * OC_CIN + ncls && db) {
-        const int o = idx - nab * OC_CIN;
-        float s = 0.0f;
-        for (int i = 0; i < nsplit; ++i)
-            for (int ab = 0; ab < 4; ++ab) s += partial[(long long)i * slab + nab * OC_CIN + o * 4 + ab];
-        db[o] = s;
+        dw[c * nab + oab] = tot;
+    } else if (db) {
+        db[idx - nw] = tot;
     }
 }

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace {
@@ -72,6 +73,19 @@ const TileCfg kCfg[] = {
     {128, 32},                                       // 8  : scalar-load variant
 };
 
+// Channels per K-step: 16 when the contraction has only 16 channels (no zero-padded MFMAs),
+// otherwise 32 (fewer barriers per FLOP).  ERFNET_IGEMM_KC = 16 / 32 forces one (experiments).
+int igemm_kc(int K)
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("ERFNET_IGEMM_KC");
+        forced = e ? atoi(e) : 0;
+    }
+    if (forced == 16 || forced == 32) return forced;
+    return K <= 16 ? 16 : 32;
+}
+
 // Choose the tile: blocks are dealt round-robin over 256 CUs, so the kernel lasts as long as the
 // CU with the most blocks: cost = ceil(blocks / 256) * BM.  Ties go to the larger tile (fewer
 // weight-tile reloads per FLOP).
@@ -105,13 +119,15 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
     d.Npad = (d.Nout + bn - 1) / bn * bn;
     int ntaps = 0;
     for (int g = 0; g < d.ngroups; ++g) ntaps = d.gtap0[g] + d.gntaps[g] > ntaps ? d.gtap0[g] + d.gntaps[g] : ntaps;
-    const int kchunks = (d.K + IG_KC - 1) / IG_KC;
-    const size_t n = (size_t)ntaps * kchunks * d.Npad * IG_KC;
+    const int KC = igemm_kc(d.K);
+    const int kchunks = (d.K + KC - 1) / KC;
+    const size_t n = (size_t)ntaps * kchunks * d.Npad * KC;
     float *wp = ar.floats(n);
     if (!wp) return fail("igemm: workspace too small for the packed weights (%zu floats)", n);
     d.wp = wp;
     pk.w = d.w; pk.wp = wp;
     pk.ntaps = ntaps; pk.K = d.K; pk.Nout = d.Nout; pk.Npad = d.Npad; pk.wsk = d.wsk; pk.wsn = d.wsn;
+    pk.kc = KC;
     for (int t = 0; t < ERF_MAX_TAPS; ++t) pk.woff[t] = d.woff[t];
     return 0;
 }
@@ -123,7 +139,7 @@ int launch_pack(const PackDesc *pks, int n, hipStream_t st)
     size_t most = 0;
     for (int i = 0; i < n; ++i) {
         b.p[i] = pks[i];
-        const size_t tot = (size_t)pks[i].ntaps * ((pks[i].K + IG_KC - 1) / IG_KC) * pks[i].Npad * IG_KC;
+        const size_t tot = (size_t)pks[i].ntaps * ((pks[i].K + pks[i].kc - 1) / pks[i].kc) * pks[i].Npad * pks[i].kc;
         most = tot > most ? tot : most;
     }
     dim3 grid((unsigned)((most + 255) / 256), n, 1);
@@ -139,17 +155,20 @@ int run_igemm(const IgemmDesc &d, hipStream_t st)
     if (M == 0) return 0;
     const TileCfg c = kCfg[d.cfg];
     dim3 grid((unsigned)((M + c.bm - 1) / c.bm), d.Npad / c.bn, d.ngroups);
-    switch (d.cfg) {
-    case 0: igemm_f32_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
-    case 1: igemm_f32_kernel<3, 1, 1, 4, true><<<grid, 256, 0, st>>>(d); break;
-    case 2: igemm_f32_kernel<2, 1, 1, 4, true><<<grid, 256, 0, st>>>(d); break;
-    case 3: igemm_f32_kernel<1, 1, 1, 4, true><<<grid, 256, 0, st>>>(d); break;
-    case 4: igemm_f32_kernel<1, 2, 4, 1, true><<<grid, 256, 0, st>>>(d); break;
-    case 5: igemm_f32_kernel<1, 1, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
-    case 6: igemm_f32_kernel<2, 1, 4, 1, true><<<grid, 256, 0, st>>>(d); break;
-    case 7: igemm_f32_kernel<1, 1, 4, 1, true><<<grid, 256, 0, st>>>(d); break;
-    default: igemm_f32_kernel<1, 1, 4, 1, false><<<grid, 256, 0, st>>>(d); break;
+#define IG_LAUNCH(KC, MW)                                                                           \
+    switch (d.cfg) {                                                                               \
+    case 0: igemm_f32_kernel<2, 2, 2, 2, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    case 1: igemm_f32_kernel<3, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    case 2: igemm_f32_kernel<2, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    case 3: igemm_f32_kernel<1, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    case 4: igemm_f32_kernel<1, 2, 4, 1, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    case 5: igemm_f32_kernel<1, 1, 2, 2, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    case 6: igemm_f32_kernel<2, 1, 4, 1, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    case 7: igemm_f32_kernel<1, 1, 4, 1, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    default: igemm_f32_kernel<1, 1, 4, 1, KC, MW, false><<<grid, 256, 0, st>>>(d); break;         \
     }
+    if (igemm_kc(d.K) == 16) { IG_LAUNCH(16, 4) } else { IG_LAUNCH(32, 2) }
+#undef IG_LAUNCH
     CHECK_LAUNCH("igemm_f32_kernel");
     return 0;
 }
@@ -478,7 +497,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         FirstDownWgradDesc d = {x, sn, sc, sh, sw, g, partial, N, H, W, Cc, Cout, (int)sp};
         first_down_wgrad_kernel<<<(unsigned)nsplit, 512, 0, st>>>(d);
         CHECK_LAUNCH("first_down_wgrad_kernel");
-        reduce_flat_kernel<<<(nw + Cc + 255) / 256, 256, 0, st>>>(partial, dw, db, (int)nsplit, nw, Cc);
+        reduce_flat_kernel<<<(nw + Cc + 31) / 32, 256, 0, st>>>(partial, dw, db, (int)nsplit, nw, Cc);
         CHECK_LAUNCH("reduce_flat_kernel");
     } else {
         WgradDesc d;
@@ -801,7 +820,7 @@ int erf_outconv_backward(const float *x, const float *w, const float *gy, float 
     }
     outconv_wgrad_kernel<<<(unsigned)nsplit, 512, 0, st>>>(d);
     CHECK_LAUNCH("outconv_wgrad_kernel");
-    outconv_wreduce_kernel<<<(slab + 255) / 256, 256, 0, st>>>(partial, dw, db, (int)nsplit, ncls);
+    outconv_wreduce_kernel<<<(slab + 31) / 32, 256, 0, st>>>(partial, dw, db, (int)nsplit, ncls);
     CHECK_LAUNCH("outconv_wreduce_kernel");
     return 0;
 }

@@ -21,17 +21,23 @@
 #pragma once
 #include "common.h"
 
-#define IG_KC 32          // channels per K-step
-#define IG_BPITCH 36      // floats per B-tile row (k) : 144 B keeps 16-B alignment, spreads banks
+// Channels per K-step KC is 16 or 32.  A-tile rows hold KC floats in 16-byte chunks, XOR-swizzled so
+// that both the staging ds_write_b128 and the fragment ds_read_b128 (lanes = rows) are free of bank
+// conflicts; B-tile rows (one per output channel) are KC + 4 floats apart for the same reason.
+template <int KC>
+__device__ __forceinline__ int a_swz(int row, int chunk)
+{
+    return KC == 32 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((row >> 2) & 3));
+}
 
 // Weights are repacked once per call from torch's layout into the order the B tile is consumed:
-//   wp[tap][k-chunk][j][32]  (k = contraction channel, j = output channel, zero padded to Npad
-//   columns and to whole 32-channel chunks), so a K-step's B tile is one contiguous run that is
+//   wp[tap][k-chunk][j][KC]  (k = contraction channel, j = output channel, zero padded to Npad
+//   columns and to whole KC-channel chunks), so a K-step's B tile is one contiguous run that is
 //   copied with 16-byte loads.  Up to four convolutions (one non_bottleneck_1d) per launch.
 struct PackDesc {
     const float *w;
     float *wp;
-    int ntaps, K, Nout, Npad, wsk, wsn;
+    int ntaps, K, Nout, Npad, wsk, wsn, kc;    // kc = channels per K-step (16 or 32)
     int woff[ERF_MAX_TAPS];
 };
 struct PackBatch {
@@ -41,15 +47,16 @@ struct PackBatch {
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackBatch b)
 {
     const PackDesc &d = b.p[blockIdx.y];
-    const int kchunks = (d.K + IG_KC - 1) / IG_KC;
-    const int total = d.ntaps * kchunks * d.Npad * IG_KC;
+    const int KC = d.kc;
+    const int kchunks = (d.K + KC - 1) / KC;
+    const int total = d.ntaps * kchunks * d.Npad * KC;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-        const int kk = idx % IG_KC;
-        int r = idx / IG_KC;
+        const int kk = idx % KC;
+        int r = idx / KC;
         const int j = r % d.Npad;
         r /= d.Npad;
         const int kc = r % kchunks, t = r / kchunks;
-        const int k = kc * IG_KC + kk;
+        const int k = kc * KC + kk;
         float v = 0.0f;
         if (k < d.K && j < d.Nout) v = d.w[d.woff[t] + (long long)k * d.wsk + (long long)j * d.wsn];
         d.wp[idx] = v;
@@ -66,14 +73,16 @@ struct RowInfo {          // per output pixel of the block tile
 // Main loop: LDS double buffering with one barrier per K-step.  In step s a wave first writes the
 // tile of step s+1 (loaded into registers during step s-1) into the buffer that was read in step
 // s-1, issues the global loads of step s+2, and then runs the MFMAs of step s from the other buffer.
-template <int WM, int WN, int GM, int GN, bool VEC>
-__global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDesc d)
+template <int WM, int WN, int GM, int GN, int KC, int MINW, bool VEC>
+__global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const IgemmDesc d)
 {
     constexpr int BM = GM * WM * 32, BN = GN * WN * 32, NT = GM * GN * 64;
-    constexpr int A_SLOTS = BM * 8, B_SLOTS = BN * 8;            // float4 slots per tile
+    constexpr int CPR = KC / 4;                                  // 16-byte chunks per tile row
+    constexpr int BPITCH = KC + 4;
+    constexpr int A_SLOTS = BM * CPR, B_SLOTS = BN * CPR;        // float4 slots per tile
     constexpr int A_PASSES = (A_SLOTS + NT - 1) / NT, B_PASSES = (B_SLOTS + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * IG_KC];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * IG_BPITCH];
+    __shared__ __attribute__((aligned(16))) float As[2][BM * KC];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * BPITCH];
     __shared__ RowInfo rows[BM];
     __shared__ int taps[ERF_MAX_TAPS * 2];   // {dh, dw} per tap, read with ds_read: keeps the tap
                                              // lookup off the vector-memory counter
@@ -108,9 +117,9 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
     }
     __syncthreads();
 
-    const int kchunks = (d.K + IG_KC - 1) / IG_KC;
-    const int tap0 = d.gtap0[grp];
-    const int nsteps = d.gntaps[grp] * kchunks;
+    const int kchunks = (d.K + KC - 1) / KC;
+    const int tap0 = __builtin_amdgcn_readfirstlane(d.gtap0[grp]);
+    const int nsteps = __builtin_amdgcn_readfirstlane(d.gntaps[grp]) * kchunks;
 
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -125,7 +134,7 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
 
     auto load_step = [&](int s) {
         const int t = tap0 + s / kchunks;
-        const int kc = s % kchunks, kc0 = kc * IG_KC;
+        const int kc = s % kchunks, kc0 = kc * KC;
         const int dh = taps[t * 2 + 0], dw = taps[t * 2 + 1];
         // Every load is issued unconditionally (an out-of-image tap or a padded channel reads a
         // valid dummy address; the value is replaced by zero when it is written to LDS): a branch
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             const int slot = tid + i * NT;
-            const int r = slot >> 3, ac = slot & 7;
+            const int r = slot / CPR, ac = slot % CPR;
             const RowInfo ri = rows[r < BM ? r : 0];
             const int ih = (ri.hs_ws & 0xffff) + dh, iw = (ri.hs_ws >> 16) + dw;
             const int kk = kc0 + ac * 4;
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
             am |= (ok ? 1u : 0u) << i;
         }
         amask = am;
-        const float *wt = d.wp + ((long long)(t * kchunks + kc) * d.Npad + j0) * IG_KC;
+        const float *wt = d.wp + ((long long)(t * kchunks + kc) * d.Npad + j0) * KC;
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int slot = tid + i * NT;
@@ -166,17 +175,17 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             const int slot = tid + i * NT;
-            const int r = slot >> 3, ac = slot & 7;
+            const int r = slot / CPR, ac = slot % CPR;
             f32x4 v = areg[i];
             if (!((amask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (A_SLOTS % NT == 0 || slot < A_SLOTS)
-                *reinterpret_cast<f32x4 *>(&As[buf][r * IG_KC + ((ac ^ ((r >> 1) & 7)) << 2)]) = v;
+                *reinterpret_cast<f32x4 *>(&As[buf][r * KC + (a_swz<KC>(r, ac) << 2)]) = v;
         }
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int slot = tid + i * NT;
             if (B_SLOTS % NT == 0 || slot < B_SLOTS)
-                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot >> 3) * IG_BPITCH + (slot & 7) * 4]) = breg[i];
+                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = breg[i];
         }
     };
 
@@ -187,25 +196,30 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         if (s + 1 < nsteps) {
+#ifndef IG_ABLATE_STORE
             store_step(buf ^ 1);
+#endif
+#ifndef IG_ABLATE_LOADS
             if (s + 2 < nsteps) load_step(s + 2);
+#endif
         }
-        const int kc0 = (s % kchunks) * IG_KC;
+        const int kc0 = (s % kchunks) * KC;
         const float *Ab = As[buf], *Bb = Bs[buf];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (kc0 + q * 8 >= d.K) break;     // wave-uniform: short last chunk (K = 16)
+        for (int q = 0; q < KC / 8; ++q) {
+            if (kc0 + q * 8 >= d.K) break;     // wave-uniform: short last chunk
             f32x4 af[WM], bf[WN];
 #pragma unroll
             for (int a = 0; a < WM; ++a) {
                 const int row = (wm * WM + a) * 32 + l31;
-                af[a] = *reinterpret_cast<const f32x4 *>(&Ab[row * IG_KC + (((2 * q + h) ^ ((row >> 1) & 7)) << 2)]);
+                af[a] = *reinterpret_cast<const f32x4 *>(&Ab[row * KC + (a_swz<KC>(row, 2 * q + h) << 2)]);
             }
 #pragma unroll
             for (int b = 0; b < WN; ++b) {
                 const int col = (wn * WN + b) * 32 + l31;
-                bf[b] = *reinterpret_cast<const f32x4 *>(&Bb[col * IG_BPITCH + q * 8 + h * 4]);
+                bf[b] = *reinterpret_cast<const f32x4 *>(&Bb[col * BPITCH + q * 8 + h * 4]);
             }
+#ifndef IG_ABLATE_MFMA
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -213,6 +227,12 @@ __global__ __launch_bounds__(GM *GN * 64, 2) void igemm_f32_kernel(const IgemmDe
 #pragma unroll
                     for (int b = 0; b < WN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[b][m], acc[a][b], 0, 0, 0);
+#else
+#pragma unroll
+            for (int a = 0; a < WM; ++a) asm volatile("" ::"v"(af[a]));
+#pragma unroll
+            for (int b = 0; b < WN; ++b) asm volatile("" ::"v"(bf[b]));
+#endif
         }
         __syncthreads();
     }
