@@ -63,7 +63,7 @@ def logits_of(out):
 def dominant_kernel_roofline(device, batch):
     """Time the dominant kernel with HIP events on the stream it is launched on.
 
-    erf_nb1d_forward in inference form issues exactly four launches of igemm_f32_kernel<2,2,2,2>
+    erf_nb1d_forward in inference form issues exactly four launches of igemm_f32_kernel<3,1,1,4,32,2,true>
     (3 taps x 128 -> 128 channels over batch x 64 x 128 pixels); algorithmic FLOPs per launch =
     2 * pixels * (3*128) * 128."""
     from erfnet_pytorch_amd import functional as hipf
@@ -96,7 +96,7 @@ def dominant_kernel_roofline(device, batch):
             traffic = None
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
-            "kernel": "igemm_f32_kernel<2,2,2,2> (1-D conv 128->128, 3 taps)",
+            "kernel": "igemm_f32_kernel<3,1,1,4,32,2,true> (1-D conv 128->128, 3 taps)",
             "us_per_launch": round(ms_per_launch * 1e3, 2), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": 2 * pixels * DOM_C * 4,
             "hbm_bound_us": round(2 * pixels * DOM_C * 4 / 8e12 * 1e6, 2)}

@@ -2,13 +2,13 @@
 //
 // Forward / data-gradient kernel (igemm_f32_kernel)
 //   M = output pixels, N = output channels, K = taps x input channels, NHWC activations.
-//   One K-step = one tap x 32 input channels.  The A tile (BM pixels x 32 channels, gathered at the
-//   tap-shifted source pixels, zero outside the image) and the B tile (32 x BN weights, gathered
-//   from torch's weight layout) are prefetched into registers while the previous step's MFMAs run,
-//   then written to a single LDS buffer:
-//     A: [BM][32] floats, 16-byte chunks XOR-swizzled with (row>>1)&7  -> conflict-free
-//        ds_write_b128 (8 lanes cover one 128-B row) and ds_read_b128 (lanes = rows);
-//     B: [BN][36] floats (k contiguous, row pitch 144 B)              -> conflict-free ds_read_b128.
+//   One K-step = one tap x KC (16 or 32) input channels.  The A tile (BM pixels x KC channels,
+//   gathered at the tap-shifted source pixels, zero outside the image) and the B tile (KC x BN
+//   pre-packed weights) are loaded into registers one step ahead and written to a double-buffered
+//   LDS image:
+//     A: [BM][KC] floats, 16-byte chunks XOR-swizzled by row  -> conflict-free ds_write_b128 and
+//        ds_read_b128 (lanes = rows);
+//     B: [BN][KC+4] floats (k contiguous, padded row pitch)   -> conflict-free ds_read_b128.
 //   A wave owns WM x WN blocks of 32x32 outputs.  A lane's ds_read_b128 delivers 4 consecutive k for
 //   its row; MFMA number m of the group takes element m, so the 2-deep k of the instruction is
 //   {8q+m, 8q+4+m} — A and B use the same permutation, the sum over k is unchanged.
@@ -196,12 +196,8 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         if (s + 1 < nsteps) {
-#ifndef IG_ABLATE_STORE
             store_step(buf ^ 1);
-#endif
-#ifndef IG_ABLATE_LOADS
             if (s + 2 < nsteps) load_step(s + 2);
-#endif
         }
         const int kc0 = (s % kchunks) * KC;
         const float *Ab = As[buf], *Bb = Bs[buf];
@@ -219,7 +215,6 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
                 const int col = (wn * WN + b) * 32 + l31;
                 bf[b] = *reinterpret_cast<const f32x4 *>(&Bb[col * BPITCH + q * 8 + h * 4]);
             }
-#ifndef IG_ABLATE_MFMA
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -227,12 +222,6 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 #pragma unroll
                     for (int b = 0; b < WN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[b][m], acc[a][b], 0, 0, 0);
-#else
-#pragma unroll
-            for (int a = 0; a < WM; ++a) asm volatile("" ::"v"(af[a]));
-#pragma unroll
-            for (int b = 0; b < WN; ++b) asm volatile("" ::"v"(bf[b]));
-#endif
         }
         __syncthreads();
     }
