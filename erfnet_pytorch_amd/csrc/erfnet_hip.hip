@@ -3,6 +3,7 @@
 #include "../../include/erfnet_hip.h"
 #include "aux_kernels.h"
 #include "igemm.h"
+#include "stream16.h"
 
 #include <atomic>
 #include <cstdarg>
@@ -101,6 +102,36 @@ int pick_cfg(long long M, int first, int count)
     return best;
 }
 
+// The 16-channel streaming kernel (conv16_kernel) takes stride-1, single-group, 3-tap convolutions
+// whose tensors allow 16-byte accesses and 32-bit element offsets.  ERFNET_NO_STREAM16=1 turns the
+// path off (experiments).
+const int kCfgStream16 = 100;
+bool stream16_enabled()
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("ERFNET_NO_STREAM16"); on = (e && atoi(e)) ? 0 : 1; }
+    return on != 0;
+}
+bool stream16_ok(const IgemmDesc &d)
+{
+    if (!stream16_enabled() || !d.vec_ok) return false;
+    if (d.K != 16 || d.Nout != 16 || d.ss != 1 || d.os != 1 || d.ngroups != 1) return false;
+    if (d.gtap0[0] != 0 || d.gntaps[0] != 3 || d.goa[0] || d.gob[0]) return false;
+    if (d.out_C % 4 || d.out_coff % 4 || !aligned16(d.out)) return false;
+    if (d.epi.res && (d.epi.res_C % 4 || d.epi.res_coff % 4 || !aligned16(d.epi.res))) return false;
+    if (d.epi.mask && (d.epi.mask_C % 4 || d.epi.mask_coff % 4 || !aligned16(d.epi.mask))) return false;
+    if (d.epi.bias && !aligned16(d.epi.bias)) return false;
+    if (d.epi.nscale && !aligned16(d.epi.nscale)) return false;
+    if (d.epi.bn.on && (!d.epi.bn.gamma || !d.epi.bn.beta || !aligned16(d.epi.bn.gamma) || !aligned16(d.epi.bn.beta) ||
+                        !aligned16(d.epi.bn.mean) || !aligned16(d.epi.bn.var))) return false;
+    const long long lim = 1LL << 29;    // buffer descriptors: at most 2^31 bytes
+    const long long pin = (long long)d.N * d.in_H * d.in_W, pout = (long long)d.N * d.out_H * d.out_W;
+    if (pin * d.in_C >= lim || pout * d.out_C >= lim) return false;
+    if (d.epi.res && pout * d.epi.res_C >= lim) return false;
+    if (d.epi.mask && pout * d.epi.mask_C >= lim) return false;
+    return true;
+}
+
 // Validate, choose the tile, reserve the packed-weight buffer and describe the packing job.
 int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
 {
@@ -111,6 +142,12 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
     if (M * d.os * d.os >= (1LL << 31) || (long long)d.N * d.in_H * d.in_W >= (1LL << 31))
         return fail("igemm: more than 2^31 pixels");
     d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && aligned16(d.in)) ? 1 : 0;
+    if (stream16_ok(d)) {          // 16 -> 16 channels: LDS-free streaming kernel, unpacked weights
+        d.cfg = kCfgStream16;
+        d.Npad = 16;
+        memset(&pk, 0, sizeof(pk));
+        return 0;
+    }
     if (!d.vec_ok) d.cfg = 8;
     else if (d.Nout > 64) d.cfg = pick_cfg(M, 0, 4);
     else if (d.Nout > 32) d.cfg = pick_cfg(M, 4, 2);
@@ -139,9 +176,11 @@ int launch_pack(const PackDesc *pks, int n, hipStream_t st)
     size_t most = 0;
     for (int i = 0; i < n; ++i) {
         b.p[i] = pks[i];
+        if (!pks[i].kc) continue;          // convolution that reads torch's layout directly
         const size_t tot = (size_t)pks[i].ntaps * ((pks[i].K + pks[i].kc - 1) / pks[i].kc) * pks[i].Npad * pks[i].kc;
         most = tot > most ? tot : most;
     }
+    if (most == 0) return 0;
     dim3 grid((unsigned)((most + 255) / 256), n, 1);
     if (grid.x > 512) grid.x = 512;
     pack_weights_kernel<<<grid, 256, 0, st>>>(b);
@@ -153,6 +192,11 @@ int run_igemm(const IgemmDesc &d, hipStream_t st)
 {
     const long long M = (long long)d.N * d.GH * d.GW;
     if (M == 0) return 0;
+    if (d.cfg == kCfgStream16) {
+        conv16_kernel<3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
+        CHECK_LAUNCH("conv16_kernel");
+        return 0;
+    }
     const TileCfg c = kCfg[d.cfg];
     dim3 grid((unsigned)((M + c.bm - 1) / c.bm), d.Npad / c.bn, d.ngroups);
 #define IG_LAUNCH(KC, MW)                                                                           \
@@ -182,6 +226,21 @@ int launch_igemm(IgemmDesc &d, Arena &ar, hipStream_t st)
     return run_igemm(d, st);
 }
 
+// Sum the slabs of a weight-gradient launch into torch's layout.
+int launch_reduce(const WgradDesc &d, float *dw, float *db, const int *woff, int wsk, int wsn,
+                  unsigned bias_taps, hipStream_t st)
+{
+    ReduceDesc r;
+    r.partial = d.partial; r.dw = dw; r.db = db;
+    r.nsplit = d.nsplit; r.ntaps = d.ntaps; r.K = d.K; r.Nout = d.Nout;
+    for (int t = 0; t < d.ntaps; ++t) r.woff[t] = woff[t];
+    r.wsk = wsk; r.wsn = wsn; r.bias_taps = bias_taps;
+    const long long tot = (long long)d.ntaps * d.K * d.Nout + d.Nout;
+    reduce_partials_kernel<<<(unsigned)((tot + 31) / 32), 256, 0, st>>>(r);
+    CHECK_LAUNCH("reduce_partials_kernel");
+    return 0;
+}
+
 // Weight gradient + slab reduction into torch's layout.  `bias_taps`: bit t set = the bias row of
 // tap t enters db (taps whose g pixels partition the gradient tensor).
 int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, int wsn,
@@ -191,6 +250,26 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     if (M >= (1LL << 31)) return fail("wgrad: more than 2^31 pixels");
     d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && d.g_C % 4 == 0 &&
                 d.g_coff % 4 == 0 && d.Nout % 4 == 0 && aligned16(d.in) && aligned16(d.g)) ? 1 : 0;
+    if (stream16_enabled() && d.K == 16 && d.Nout == 16 && d.ntaps == 3 && d.ss == 1 && d.os == 1 &&
+        d.in_H == d.GH && d.in_W == d.GW && d.g_H == d.GH && d.g_W == d.GW && d.GW >= 16 &&
+        M * d.in_C < (1LL << 29) && M * d.g_C < (1LL << 29) && !d.toa[0] && !d.tob[0] && !d.toa[1] &&
+        !d.tob[1] && !d.toa[2] && !d.tob[2]) {
+        constexpr int NW = 8;
+        const size_t slab = 3 * 256 + 3 * 16;
+        long long nsplit = (M + NW * 64 - 1) / (NW * 64);          // >= 4 MFMA groups per wave
+        if (nsplit > 512) nsplit = 512;
+        if (nsplit < 1) nsplit = 1;
+        long long sp = (M + nsplit - 1) / nsplit;
+        sp = (sp + NW * 16 - 1) / (NW * 16) * (NW * 16);
+        nsplit = (M + sp - 1) / sp;
+        d.nsplit = (int)nsplit;
+        d.split_pixels = (int)sp;
+        d.partial = ar.floats(slab * nsplit);
+        if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
+        wgrad16_kernel<3, NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(d);
+        CHECK_LAUNCH("wgrad16_kernel");
+        return launch_reduce(d, dw, db, woff, wsk, wsn, bias_taps, st);
+    }
     int IBLK, JBLK, cfg;
     if (!d.vec_ok) { IBLK = 32; JBLK = 32; cfg = 7; }
     else if (d.K > 64 && d.Nout > 64) { IBLK = 128; JBLK = 128; cfg = 0; }
@@ -230,15 +309,7 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     default: wgrad_f32_kernel<1, 1, 1, 1, false><<<grid, 64, 0, st>>>(d); break;
     }
     CHECK_LAUNCH("wgrad_f32_kernel");
-    ReduceDesc r;
-    r.partial = d.partial; r.dw = dw; r.db = db;
-    r.nsplit = d.nsplit; r.ntaps = d.ntaps; r.K = d.K; r.Nout = d.Nout;
-    for (int t = 0; t < d.ntaps; ++t) r.woff[t] = woff[t];
-    r.wsk = wsk; r.wsn = wsn; r.bias_taps = bias_taps;
-    const long long tot = (long long)d.ntaps * d.K * d.Nout + d.Nout;
-    reduce_partials_kernel<<<(unsigned)((tot + 31) / 32), 256, 0, st>>>(r);
-    CHECK_LAUNCH("reduce_partials_kernel");
-    return 0;
+    return launch_reduce(d, dw, db, woff, wsk, wsn, bias_taps, st);
 }
 
 unsigned grid_for(long long work_items, int per_block = 256, unsigned cap = 8192)
