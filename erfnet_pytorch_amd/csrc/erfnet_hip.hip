@@ -32,6 +32,56 @@ int fail(const char *fmt, ...)
         g_launches.fetch_add(1, std::memory_order_relaxed);                                        \
     } while (0)
 
+// Helper stream for work that is off the critical path of a backward call (weight gradients run
+// beside the data-gradient chain and fill the launch / write-back gaps of its kernels).  One low
+// priority stream and a few events per host thread and device, created on first use; every call
+// that forks work onto it joins it back into the caller's stream before returning, so from the
+// caller's side all work is ordered on the stream it passed.  ERFNET_NO_SIDE_STREAM=1 disables it.
+struct Side {
+    hipStream_t s = nullptr;
+    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join = nullptr;
+    int state = 0;      // 0 = not created, 1 = ready, -1 = unavailable
+};
+thread_local Side g_side[32];
+
+Side *side_stream()
+{
+    static int enabled = -1;
+    if (enabled < 0) { const char *e = getenv("ERFNET_NO_SIDE_STREAM"); enabled = (e && atoi(e)) ? 0 : 1; }
+    if (!enabled) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
+    Side &sd = g_side[dev];
+    if (sd.state == 0) {
+        sd.state = -1;
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; }
+        if (hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
+        bool ok = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&sd.fork[i], hipEventDisableTiming) == hipSuccess;
+        if (ok) sd.state = 1;
+    }
+    return sd.state == 1 ? &sd : nullptr;
+}
+// Work queued on the returned stream starts after everything queued on `main` so far.
+hipStream_t side_fork(Side *sd, int i, hipStream_t main)
+{
+    if (!sd) return main;
+    if (hipEventRecord(sd->fork[i], main) != hipSuccess || hipStreamWaitEvent(sd->s, sd->fork[i], 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return main;
+    }
+    return sd->s;
+}
+// Everything queued on the side stream so far completes before later work on `main`.
+int side_join(Side *sd, hipStream_t main)
+{
+    if (!sd) return 0;
+    if (hipEventRecord(sd->join, sd->s) != hipSuccess || hipStreamWaitEvent(main, sd->join, 0) != hipSuccess)
+        return fail("side stream join failed: %s", hipGetErrorString(hipGetLastError()));
+    return 0;
+}
+
 // Bump allocator over the caller's workspace (256-byte granules).
 struct Arena {
     char *base;
@@ -283,11 +333,13 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     d.jtiles = (d.Nout + JBLK - 1) / JBLK;
     const int tiles = d.ntaps * d.itiles * d.jtiles;
     const size_t slab = (size_t)d.ntaps * d.K * d.Nout + (size_t)d.ntaps * d.Nout;
-    long long nsplit = 768 / tiles;                       // about three blocks per CU
+    static int target_blocks = 0;
+    if (!target_blocks) { const char *e = getenv("ERFNET_WGRAD_BLOCKS"); target_blocks = e ? atoi(e) : 768; }
+    long long nsplit = target_blocks / tiles;             // about three blocks per CU
     if (nsplit < 1) nsplit = 1;
     const long long max_by_work = (M + 255) / 256;       // at least 8 MFMA k-tiles per block
     if (nsplit > max_by_work) nsplit = max_by_work;
-    const long long max_by_mem = (long long)((24u << 20) / (slab * sizeof(float)));
+    const long long max_by_mem = (long long)((64u << 20) / (slab * sizeof(float)));
     if (nsplit > max_by_mem) nsplit = max_by_mem;
     if (nsplit < 1) nsplit = 1;
     long long sp = (M + nsplit - 1) / nsplit;
@@ -474,8 +526,8 @@ unsigned long long erf_launch_count(void) { return g_launches.load(); }
 
 size_t erf_workspace_bytes(long long n_pixels, int max_c)
 {
-    // three gradient/activation temporaries + weight-gradient slabs + BatchNorm sums + slack
-    return (size_t)n_pixels * (size_t)max_c * sizeof(float) * 3 + (size_t)(56u << 20);
+    // six gradient/activation temporaries + weight-gradient slabs + BatchNorm sums + slack
+    return (size_t)n_pixels * (size_t)max_c * sizeof(float) * 6 + (size_t)(96u << 20);
 }
 
 // ================================================================================ Downsampler
@@ -551,6 +603,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
     const int mode = bn_mode(bn);
     float *g = ar.floats((size_t)Mo * Cout);
     if (!g) return fail("DownsamplerBlock backward: workspace too small");
+    Side *sd = nullptr;
     if (mode) {
         if (bn_backward(bn, pre, gy, y, nullptr, g, dgamma, dbeta, Mo, Cout, Ho * Wo, ar, st)) return 1;
     } else {
@@ -579,7 +632,8 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         int woff[9];
         for (int t = 0; t < 9; ++t) { d.tdh[t] = t / 3 - 1; d.tdw[t] = t % 3 - 1; woff[t] = t; }
         d.g_H = Ho; d.g_W = Wo; d.g_C = Cout; d.Nout = Cc;
-        if (launch_wgrad(d, dw, db, woff, 9, Cin * 9, 1u, ar, st)) return 1;
+        sd = dx ? side_stream() : nullptr;        // beside the data gradient, when there is one
+        if (launch_wgrad(d, dw, db, woff, 9, Cin * 9, 1u, ar, side_fork(sd, 0, st))) return 1;
     }
     if (dx) {
         // dx is NHWC [N,H,W,Cin]: max-pool gradient first, then the conv data gradient on top.
@@ -605,7 +659,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         d.wsk = Cin * 9; d.wsn = 9;   // W[co][ci][kh][kw]: k = co, j = ci
         if (launch_igemm(d, ar, st)) return 1;
     }
-    return 0;
+    return side_join(sd, st);
 }
 
 // ================================================================================ non_bottleneck_1d
@@ -700,66 +754,77 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     const size_t nel = (size_t)M * C;
     const int m1 = bn_mode(bn1), m2 = bn_mode(bn2);
     const float *t1 = save[0], *p2 = save[1], *t2 = save[2], *t3 = save[3], *p4 = save[4];
-    float *g4 = ar.floats(nel), *ga = ar.floats(nel), *gb = ar.floats(nel);
-    if (!g4 || !ga || !gb) return fail("non_bottleneck_1d backward: workspace too small");
+    // Every tensor of the gradient chain gets a buffer of its own, so the weight gradients (helper
+    // stream) can read them while the chain moves on:
+    //   g4 = gy*(y>0) -> [gs = bn2'/dropout'(g4)] -> gb -> ga -> [gn = bn1'(ga)] -> g1 -> dx
+    float *g4 = ar.floats(nel), *ga = ar.floats(nel), *gb = ar.floats(nel), *g1 = ar.floats(nel);
+    float *gs = (m2 || drop_scale) ? ar.floats(nel) : g4;
+    float *gn = m1 ? ar.floats(nel) : ga;
+    if (!g4 || !ga || !gb || !g1 || !gs || !gn) return fail("non_bottleneck_1d backward: workspace too small");
     const int woff[3] = {0, 1, 2};
     WgradDesc wd;
 
-    // gradient buffers of the chain: conv1x3_2 <- gin, conv3x1_2 <- gb, conv1x3_1 <- g2, conv3x1_1 <- g1
-    const float *gin = (m2 || drop_scale) ? ga : g4;
-    const float *g2 = m1 ? gb : ga;
-    float *g1 = m1 ? ga : gb;
     IgemmDesc d[4];
     PackDesc pk[4];
-    conv1d_desc(d[3], gin, w[3], gb, N, C, H, W, 1, dil, true);     // masked by t3 > 0
+    conv1d_desc(d[3], gs, w[3], gb, N, C, H, W, 1, dil, true);      // masked by t3 > 0
     d[3].epi.mask = t3; d[3].epi.mask_C = C;
     conv1d_desc(d[2], gb, w[2], ga, N, C, H, W, 0, dil, true);      // masked by t2 > 0
     d[2].epi.mask = t2; d[2].epi.mask_C = C;
-    conv1d_desc(d[1], g2, w[1], g1, N, C, H, W, 1, 1, true);        // masked by t1 > 0
+    conv1d_desc(d[1], gn, w[1], g1, N, C, H, W, 1, 1, true);        // masked by t1 > 0
     d[1].epi.mask = t1; d[1].epi.mask_C = C;
     conv1d_desc(d[0], g1, w[0], dx, N, C, H, W, 0, 1, true);        // + g4 (residual path)
     d[0].epi.res = g4; d[0].epi.res_C = C;
     for (int i = 0; i < 4; ++i)
         if (plan_igemm(d[i], ar, pk[i])) return 1;
     if (launch_pack(pk, 4, st)) return 1;
-    const size_t ws_mark = ar.off;       // everything below is per-convolution scratch, reused
+    // BatchNorm scratch (caller's stream) first, then the slab region the four weight gradients
+    // share: they run one after the other on one stream.
+    const size_t bn_bytes = 2 * (sizeof(double) * 2 * (size_t)C + 256);
+    void *pbn = ar.take(bn_bytes);
+    if (!pbn) return fail("non_bottleneck_1d backward: workspace too small");
+    Arena bn_ar(pbn, bn_bytes);
+    const size_t ws_mark = ar.off;
+    Side *sd = side_stream();
 
     // g4 = gy * (y > 0): gradient of the residual sum (goes to x unchanged and into the conv branch)
     if (launch_mask(gy, y, g4, M, C, st)) return 1;
     if (m2) {
-        if (bn_backward(bn2, p4, g4, nullptr, drop_scale, ga, dgamma ? dgamma[1] : nullptr,
-                        dbeta ? dbeta[1] : nullptr, M, C, H * W, ar, st)) return 1;
+        if (bn_backward(bn2, p4, g4, nullptr, drop_scale, gs, dgamma ? dgamma[1] : nullptr,
+                        dbeta ? dbeta[1] : nullptr, M, C, H * W, bn_ar, st)) return 1;
     } else if (drop_scale) {
         Epilogue e = kNoEpi;
         e.nscale = drop_scale;
-        if (launch_elt(g4, ga, e, M, C, H * W, st)) return 1;
+        if (launch_elt(g4, gs, e, M, C, H * W, st)) return 1;
     }
-    // conv1x3_2: weight gradient from (t3, gin); data gradient -> gb
+    // conv1x3_2: weight gradient from (t3, gs); data gradient -> gb
+    hipStream_t ss = side_fork(sd, 0, st);
     ar.off = ws_mark;
-    wgrad1d_desc(wd, t3, gin, N, C, H, W, 1, dil);
-    if (launch_wgrad(wd, dw[3], db[3], woff, 3, C * 3, 1u, ar, st)) return 1;
+    wgrad1d_desc(wd, t3, gs, N, C, H, W, 1, dil);
+    if (launch_wgrad(wd, dw[3], db[3], woff, 3, C * 3, 1u, ar, ss)) return 1;
     if (run_igemm(d[3], st)) return 1;
     // conv3x1_2: (t2, gb) -> ga
+    ss = side_fork(sd, 1, st);
     ar.off = ws_mark;
     wgrad1d_desc(wd, t2, gb, N, C, H, W, 0, dil);
-    if (launch_wgrad(wd, dw[2], db[2], woff, 3, C * 3, 1u, ar, st)) return 1;
+    if (launch_wgrad(wd, dw[2], db[2], woff, 3, C * 3, 1u, ar, ss)) return 1;
     if (run_igemm(d[2], st)) return 1;
     if (m1) {
-        ar.off = ws_mark;
-        if (bn_backward(bn1, p2, ga, nullptr, nullptr, gb, dgamma ? dgamma[0] : nullptr,
-                        dbeta ? dbeta[0] : nullptr, M, C, H * W, ar, st)) return 1;
+        if (bn_backward(bn1, p2, ga, nullptr, nullptr, gn, dgamma ? dgamma[0] : nullptr,
+                        dbeta ? dbeta[0] : nullptr, M, C, H * W, bn_ar, st)) return 1;
     }
-    // conv1x3_1: (t1, g2) -> g1
+    // conv1x3_1: (t1, gn) -> g1
+    ss = side_fork(sd, 2, st);
     ar.off = ws_mark;
-    wgrad1d_desc(wd, t1, g2, N, C, H, W, 1, 1);
-    if (launch_wgrad(wd, dw[1], db[1], woff, 3, C * 3, 1u, ar, st)) return 1;
+    wgrad1d_desc(wd, t1, gn, N, C, H, W, 1, 1);
+    if (launch_wgrad(wd, dw[1], db[1], woff, 3, C * 3, 1u, ar, ss)) return 1;
     if (run_igemm(d[1], st)) return 1;
     // conv3x1_1: (x, g1) -> dx = dgrad + g4
+    ss = side_fork(sd, 3, st);
     ar.off = ws_mark;
     wgrad1d_desc(wd, x, g1, N, C, H, W, 0, 1);
-    if (launch_wgrad(wd, dw[0], db[0], woff, 3, C * 3, 1u, ar, st)) return 1;
+    if (launch_wgrad(wd, dw[0], db[0], woff, 3, C * 3, 1u, ar, ss)) return 1;
     if (run_igemm(d[0], st)) return 1;
-    return 0;
+    return side_join(sd, st);
 }
 
 // ================================================================================ Upsampler
@@ -823,7 +888,8 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
         if (launch_mask(gy, y, g, Mo, Cout, st)) return 1;
     }
     const ParityTaps pt = parity_taps();
-    {   // weight gradient over the parity classes
+    Side *sd = dx ? side_stream() : nullptr;
+    {   // weight gradient over the parity classes (beside the data gradient)
         WgradDesc d;
         memset(&d, 0, sizeof(d));
         d.in = x; d.g = g;
@@ -835,7 +901,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
             woff[t] = pt.kh[t] * 3 + pt.kw[t];
         }
         d.g_H = 2 * H; d.g_W = 2 * W; d.g_C = Cout; d.Nout = Cout;
-        if (launch_wgrad(d, dw, db, woff, Cout * 9, 9, pt.rep_mask, ar, st)) return 1;
+        if (launch_wgrad(d, dw, db, woff, Cout * 9, 9, pt.rep_mask, ar, side_fork(sd, 0, st))) return 1;
     }
     if (dx) {   // data gradient = ordinary 3x3 stride-2 convolution of g
         IgemmDesc d;
@@ -849,7 +915,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
         d.wsk = 9; d.wsn = Cout * 9;   // W[ci][co][kh][kw]: k = co, j = ci
         if (launch_igemm(d, ar, st)) return 1;
     }
-    return 0;
+    return side_join(sd, st);
 }
 
 // ================================================================================ output conv
@@ -951,7 +1017,8 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
     int woff[9];
     conv2d_taps(k, wd.tdh, wd.tdw, woff, false);
     wd.g_H = H; wd.g_W = W; wd.g_C = Cout; wd.Nout = Cout;
-    if (launch_wgrad(wd, dw, db, woff, k * k, Cin * k * k, 1u, ar, st)) return 1;
+    Side *sd = dx ? side_stream() : nullptr;
+    if (launch_wgrad(wd, dw, db, woff, k * k, Cin * k * k, 1u, ar, side_fork(sd, 0, st))) return 1;
     if (dx) {
         IgemmDesc d;
         zero_desc(d);
@@ -964,7 +1031,7 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
         d.wsk = Cin * k * k; d.wsn = k * k;
         if (launch_igemm(d, ar, st)) return 1;
     }
-    return 0;
+    return side_join(sd, st);
 }
 
 }  // extern "C"

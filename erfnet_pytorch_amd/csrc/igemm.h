@@ -70,9 +70,10 @@ struct RowInfo {          // per output pixel of the block tile
     int n;
 };
 
-// Main loop: LDS double buffering with one barrier per K-step.  In step s a wave first writes the
-// tile of step s+1 (loaded into registers during step s-1) into the buffer that was read in step
-// s-1, issues the global loads of step s+2, and then runs the MFMAs of step s from the other buffer.
+// Main loop: LDS double buffering with one barrier per K-step and global loads two steps ahead of
+// their LDS write.  In step s a wave first writes the tile of step s+1 (in registers since step
+// s-2) into the buffer that was read in step s-1, issues the global loads of step s+3 into the
+// registers just freed, and then runs the MFMAs of step s from the other buffer.
 template <int WM, int WN, int GM, int GN, int KC, int MINW, bool VEC>
 __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const IgemmDesc d)
 {
@@ -129,10 +130,15 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    f32x4 areg[A_PASSES], breg[B_PASSES];
-    unsigned amask = 0;              // bit i: pass i holds real data (else it is stored as zero)
+    // Two register sets: the tile of step k travels through set k & 1, so its global loads have two
+    // whole K-steps to land before they are written to LDS.
+    struct Stage {
+        f32x4 a[A_PASSES], b[B_PASSES];
+        unsigned amask;          // bit i: pass i holds real data (else it is stored as zero)
+    };
+    Stage st0, st1;
 
-    auto load_step = [&](int s) {
+    auto load_step = [&](int s, Stage &R) {
         const int t = tap0 + s / kchunks;
         const int kc = s % kchunks, kc0 = kc * KC;
         const int dh = taps[t * 2 + 0], dw = taps[t * 2 + 1];
@@ -159,25 +165,25 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (ok && kk + e < d.K) ? p[e] : 0.0f;
             }
-            areg[i] = v;
+            R.a[i] = v;
             am |= (ok ? 1u : 0u) << i;
         }
-        amask = am;
+        R.amask = am;
         const float *wt = d.wp + ((long long)(t * kchunks + kc) * d.Npad + j0) * KC;
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int slot = tid + i * NT;
-            breg[i] = *reinterpret_cast<const f32x4 *>(wt + (slot < B_SLOTS ? slot : 0) * 4);
+            R.b[i] = *reinterpret_cast<const f32x4 *>(wt + (slot < B_SLOTS ? slot : 0) * 4);
         }
     };
 
-    auto store_step = [&](int buf) {
+    auto store_step = [&](int buf, const Stage &R) {
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             const int slot = tid + i * NT;
             const int r = slot / CPR, ac = slot % CPR;
-            f32x4 v = areg[i];
-            if (!((amask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 v = R.a[i];
+            if (!((R.amask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (A_SLOTS % NT == 0 || slot < A_SLOTS)
                 *reinterpret_cast<f32x4 *>(&As[buf][r * KC + (a_swz<KC>(r, ac) << 2)]) = v;
         }
@@ -185,20 +191,16 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
         for (int i = 0; i < B_PASSES; ++i) {
             const int slot = tid + i * NT;
             if (B_SLOTS % NT == 0 || slot < B_SLOTS)
-                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = breg[i];
+                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = R.b[i];
         }
     };
 
-    load_step(0);
-    store_step(0);
-    if (nsteps > 1) load_step(1);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
+    // One K-step: write tile s+1 (held in R) to the other LDS buffer, reuse R for the loads of
+    // tile s+3, run the MFMAs of tile s.  One barrier per step.
+    auto k_step = [&](int s, Stage &R) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) {
-            store_step(buf ^ 1);
-            if (s + 2 < nsteps) load_step(s + 2);
-        }
+        if (s + 1 < nsteps) store_step(buf ^ 1, R);
+        if (s + 3 < nsteps) load_step(s + 3, R);
         const int kc0 = (s % kchunks) * KC;
         const float *Ab = As[buf], *Bb = Bs[buf];
 #pragma unroll
@@ -224,41 +226,69 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[b][m], acc[a][b], 0, 0, 0);
         }
         __syncthreads();
+    };
+
+    load_step(0, st0);
+    store_step(0, st0);
+    if (nsteps > 1) load_step(1, st1);
+    if (nsteps > 2) load_step(2, st0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; s += 2) {
+        k_step(s, st1);                          // tile s+1 lives in set 1 (s even)
+        if (s + 1 < nsteps) k_step(s + 1, st0);
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // All global accesses go through buffer descriptors with 32-bit byte offsets: a row beyond M,
+    // a padded column or an absent optional tensor (zero records) is an out-of-range access, which
+    // loads zero and drops the store, so the code has no per-element branch or 64-bit address.
+    const unsigned Pout = (unsigned)d.N * d.out_H * d.out_W;
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, Pout * d.out_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, (unsigned)d.N * d.Nout * 4u);
+    const bool has_mask = d.epi.mask != nullptr, has_ns = d.epi.nscale != nullptr, relu = d.epi.relu != 0;
+    // per-column constants: channel affine and the "column is padding" offset bit
+    float sc[WN], sh[WN];
+    unsigned cbad[WN], cc[WN];
 #pragma unroll
     for (int b = 0; b < WN; ++b) {
         const int c = j0 + (wn * WN + b) * 32 + l31;
-        if (c >= d.Nout) continue;
-        float sc, sh;
-        epi_channel_affine(d.epi, c, sc, sh);
+        const bool cok = c < d.Nout;
+        cc[b] = (unsigned)c;
+        cbad[b] = cok ? 0u : ERF_OOB;
+        epi_channel_affine(d.epi, cok ? c : 0, sc[b], sh[b]);
+    }
 #pragma unroll
-        for (int a = 0; a < WM; ++a) {
-            // gather the epilogue operands of all 16 rows first (unconditional loads), then store
-            int opix[16], on[16];
+    for (int a = 0; a < WM; ++a) {
+        // rows beyond M carry out_pix = -1: the sign bit, kept as bit 31 of every byte offset,
+        // puts the access out of range (plain bit arithmetic: a select here turns into branches)
+        unsigned opx[16], onn[16], rbad[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const RowInfo ri = rows[row];
+            opx[r] = (unsigned)ri.out_pix;
+            rbad[r] = (unsigned)(ri.out_pix >> 31) & ERF_OOB;
+            onn[r] = (unsigned)ri.n * d.Nout;
+        }
+#pragma unroll
+        for (int b = 0; b < WN; ++b) {
             float rres[16], rmask[16], rns[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const RowInfo ri = rows[row];
-                opix[r] = ri.out_pix;
-                on[r] = ri.n;
+                const unsigned bad = rbad[r] | cbad[b];
+                rres[r] = buf_load1(r_res, ((opx[r] * d.epi.res_C + d.epi.res_coff + cc[b]) * 4u) | bad);
+                rmask[r] = buf_load1(r_mask, ((opx[r] * d.epi.mask_C + d.epi.mask_coff + cc[b]) * 4u) | bad);
+                rns[r] = buf_load1(r_ns, ((onn[r] + cc[b]) * 4u) | bad);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long px = opix[r] < 0 ? 0 : opix[r];
-                rres[r] = d.epi.res ? d.epi.res[px * d.epi.res_C + d.epi.res_coff + c] : 0.0f;
-                rmask[r] = d.epi.mask ? d.epi.mask[px * d.epi.mask_C + d.epi.mask_coff + c] : 1.0f;
-                rns[r] = d.epi.nscale ? d.epi.nscale[(long long)on[r] * d.Nout + c] : 1.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[a][b][r] * sc + sh;
-                v = v * rns[r] + rres[r];
-                if (d.epi.relu) v = fmaxf(v, 0.0f);
-                v = rmask[r] > 0.0f ? v : 0.0f;
-                if (opix[r] >= 0) d.out[(long long)opix[r] * d.out_C + d.out_coff + c] = v;
+                float v = acc[a][b][r] * sc[b] + sh[b];
+                v = (has_ns ? v * rns[r] : v) + rres[r];
+                if (relu) v = fmaxf(v, 0.0f);
+                v = (!has_mask || rmask[r] > 0.0f) ? v : 0.0f;
+                buf_store1(r_out, ((opx[r] * d.out_C + d.out_coff + cc[b]) * 4u) | rbad[r] | cbad[b], v);
             }
         }
     }
@@ -276,8 +306,9 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
     constexpr int PM = 32;
     constexpr int XV = PM * IBLK / 4, GV = PM * JBLK / 4;        // float4 slots per tile
     constexpr int XP = (XV + NT - 1) / NT, GP = (GV + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) float Xs[PM * IBLK];
-    __shared__ __attribute__((aligned(16))) float Gs[PM * JBLK];
+    constexpr int XPITCH = IBLK, GPITCH = JBLK;
+    __shared__ __attribute__((aligned(16))) float Xs[PM * XPITCH];
+    __shared__ __attribute__((aligned(16))) float Gs[PM * GPITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave / GJ, wj = wave % GJ;
@@ -311,8 +342,39 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
     f32x4 xreg[XP], greg[GP];
     unsigned xmask = 0, gmask = 0;
 
+    // Pixel table of the step being loaded: the first PM threads each follow one pixel of the
+    // 32-pixel window (coordinates advanced incrementally, one division pair in the prologue),
+    // everybody else reads the table instead of dividing per load.
+    //   x: n*in_H*in_W (source image base, -1 = beyond the slab)   y: gi*ss   z: gj*ss
+    //   w: pixel index of the gradient tensor for this tap
+    __shared__ int4 ptab[2][PM];
+    unsigned tn = 0, tgi = 0, tgj = 0;
+    if (tid < PM) {
+        const unsigned m = mbeg + tid;
+        const unsigned mm = m < M ? m : 0;
+        tn = mm / GHW;
+        const unsigned rem = mm - tn * GHW;
+        tgi = rem / (unsigned)d.GW;
+        tgj = rem - tgi * d.GW;
+    }
+    auto table_step = [&](int s) {      // threads < PM: publish pixel mbeg + s*PM + tid, then advance
+        if (tid < PM) {
+            const unsigned m = mbeg + (unsigned)s * PM + tid;
+            int4 e;
+            e.x = m < mend ? (int)(tn * d.in_H * d.in_W) : -1;
+            e.y = (int)tgi * d.ss;
+            e.z = (int)tgj * d.ss;
+            e.w = (int)((tn * d.g_H + tgi * d.os + oa) * d.g_W + tgj * d.os + ob);
+            ptab[s & 1][tid] = e;
+            tgj += PM;
+            while (tgj >= (unsigned)d.GW) {
+                tgj -= d.GW;
+                if (++tgi == (unsigned)d.GH) { tgi = 0; ++tn; }
+            }
+        }
+    };
+
     auto load_step = [&](int s) {
-        const unsigned mb = mbeg + (unsigned)s * PM;
         // unconditional loads with a dummy address for masked slots, zeroed at the LDS store
         // (see igemm_f32_kernel)
         unsigned xm = 0, gm = 0;
@@ -320,20 +382,17 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
         for (int i = 0; i < XP; ++i) {
             const int slot = tid + i * NT;
             const int p = slot / (IBLK / 4), c = (slot % (IBLK / 4)) * 4;
-            const unsigned m = mb + p;
-            bool ok = slot < XV && m < mend && i0 + c < d.K;
-            const unsigned mm = ok ? m : mbeg;
-            const unsigned n = mm / GHW, rem = mm - n * GHW;
-            const unsigned gi = rem / (unsigned)d.GW, gj = rem - gi * d.GW;
-            const int ih = (int)gi * d.ss + dh, iw = (int)gj * d.ss + dw;
-            ok = ok && (unsigned)ih < (unsigned)d.in_H && (unsigned)iw < (unsigned)d.in_W;
-            const long long off = ok ? ((long long)((n * d.in_H + ih) * d.in_W + iw) * d.in_C + d.in_coff + i0 + c) : 0;
+            const int4 e = ptab[s & 1][p < PM ? p : 0];
+            const int ih = e.y + dh, iw = e.z + dw;
+            const bool ok = slot < XV && e.x >= 0 && i0 + c < d.K && (unsigned)ih < (unsigned)d.in_H &&
+                            (unsigned)iw < (unsigned)d.in_W;
+            const long long off = ok ? ((long long)(e.x + ih * d.in_W + iw) * d.in_C + d.in_coff + i0 + c) : 0;
             const float *px = d.in + off;
             f32x4 v;
             if (VEC) v = *reinterpret_cast<const f32x4 *>(px);
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (ok && i0 + c + e < d.K) ? px[e] : 0.0f;
+                for (int q = 0; q < 4; ++q) v[q] = (ok && i0 + c + q < d.K) ? px[q] : 0.0f;
             }
             xreg[i] = v;
             xm |= (ok ? 1u : 0u) << i;
@@ -343,18 +402,15 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
         for (int i = 0; i < GP; ++i) {
             const int slot = tid + i * NT;
             const int p = slot / (JBLK / 4), c = (slot % (JBLK / 4)) * 4;
-            const unsigned m = mb + p;
-            const bool ok = slot < GV && m < mend && j0 + c < d.Nout;
-            const unsigned mm = ok ? m : mbeg;
-            const unsigned n = mm / GHW, rem = mm - n * GHW;
-            const unsigned gi = rem / (unsigned)d.GW, gj = rem - gi * d.GW;
-            const long long off = ok ? ((long long)((n * d.g_H + gi * d.os + oa) * d.g_W + gj * d.os + ob) * d.g_C + d.g_coff + j0 + c) : 0;
+            const int4 e = ptab[s & 1][p < PM ? p : 0];
+            const bool ok = slot < GV && e.x >= 0 && j0 + c < d.Nout;
+            const long long off = ok ? ((long long)e.w * d.g_C + d.g_coff + j0 + c) : 0;
             const float *pg = d.g + off;
             f32x4 v;
             if (VEC) v = *reinterpret_cast<const f32x4 *>(pg);
             else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (ok && j0 + c + e < d.Nout) ? pg[e] : 0.0f;
+                for (int q = 0; q < 4; ++q) v[q] = (ok && j0 + c + q < d.Nout) ? pg[q] : 0.0f;
             }
             greg[i] = v;
             gm |= (ok ? 1u : 0u) << i;
@@ -367,20 +423,25 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
             const int slot = tid + i * NT;
             f32x4 v = xreg[i];
             if (!((xmask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (slot < XV) *reinterpret_cast<f32x4 *>(&Xs[slot * 4]) = v;
+            if (slot < XV) *reinterpret_cast<f32x4 *>(&Xs[(slot / (IBLK / 4)) * XPITCH + (slot % (IBLK / 4)) * 4]) = v;
         }
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
             const int slot = tid + i * NT;
             f32x4 v = greg[i];
             if (!((gmask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (slot < GV) *reinterpret_cast<f32x4 *>(&Gs[slot * 4]) = v;
+            if (slot < GV) *reinterpret_cast<f32x4 *>(&Gs[(slot / (JBLK / 4)) * GPITCH + (slot % (JBLK / 4)) * 4]) = v;
         }
     };
 
-    if (nsteps > 0) load_step(0);
+    if (nsteps > 0) {
+        table_step(0);
+        __syncthreads();
+        load_step(0);
+    }
     for (int s = 0; s < nsteps; ++s) {
         store_step();
+        if (s + 1 < nsteps) table_step(s + 1);
         __syncthreads();
         if (s + 1 < nsteps) load_step(s + 1);
 #pragma unroll 4
@@ -388,10 +449,10 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
             const int p = 2 * pp + h;
             float af[IB], bf[JB];
 #pragma unroll
-            for (int a = 0; a < IB; ++a) af[a] = Xs[p * IBLK + (wi * IB + a) * 32 + l31];
+            for (int a = 0; a < IB; ++a) af[a] = Xs[p * XPITCH + (wi * IB + a) * 32 + l31];
 #pragma unroll
             for (int b = 0; b < JB; ++b) {
-                bf[b] = Gs[p * JBLK + (wj * JB + b) * 32 + l31];
+                bf[b] = Gs[p * GPITCH + (wj * JB + b) * 32 + l31];
                 bsum[b] += bf[b];
             }
 #pragma unroll

@@ -11,28 +11,6 @@
 #pragma once
 #include "common.h"
 
-// Global loads go through buffer descriptors: a lane whose operand is masked (tap outside the
-// image, pixel beyond the range, optional tensor absent) presents an out-of-range offset and the
-// hardware returns zero without touching memory.  Every load is therefore unconditional and its
-// value is used as it is — no branch around a load and no select behind it, either of which makes
-// the compiler wait for each load separately.  Descriptors cover at most 2^31 bytes (host check).
-#define ERF_OOB 0x80000000u
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, unsigned bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)(p ? bytes : 0u), 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
-{
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
-    return __builtin_bit_cast(f32x4, v);
-}
-__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
-}
-
 // Forward / data gradient:  out[pix][j] = epi( sum_t sum_k in[src(pix,t)][k] * W[t][k][j] ).
 // Computed transposed, D[j][pix] = sum_k Wt[j][k] * X[k][pix], so that a lane's four D registers
 // are four consecutive channels of one pixel: loads, epilogue operands and stores are all one
