@@ -83,7 +83,14 @@ struct WgradDesc {
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, unsigned bytes)
 {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, (int)(p ? bytes : 0u), 0x00020000);
+    // readfirstlane makes the descriptor words provably wave-uniform; otherwise the compiler
+    // wraps every buffer access in a per-lane "waterfall" loop
+    const uintptr_t a = (uintptr_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned n = __builtin_amdgcn_readfirstlane(p ? bytes : 0u);
+    float *q = reinterpret_cast<float *>(((uintptr_t)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)n, 0x00020000);
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {

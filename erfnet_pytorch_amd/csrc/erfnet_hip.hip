@@ -191,6 +191,12 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
         return fail("igemm: spatial extent too large");
     if (M * d.os * d.os >= (1LL << 31) || (long long)d.N * d.in_H * d.in_W >= (1LL << 31))
         return fail("igemm: more than 2^31 pixels");
+    {   // buffer descriptors address at most 2^31 bytes per tensor
+        const long long lim = 1LL << 29, pin = (long long)d.N * d.in_H * d.in_W, pout = (long long)d.N * d.out_H * d.out_W;
+        if (pin * d.in_C >= lim || pout * d.out_C >= lim || (d.epi.res && pout * d.epi.res_C >= lim) ||
+            (d.epi.mask && pout * d.epi.mask_C >= lim))
+            return fail("igemm: tensors of 2 GiB or more are not supported");
+    }
     d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && aligned16(d.in)) ? 1 : 0;
     if (stream16_ok(d)) {          // 16 -> 16 channels: LDS-free streaming kernel, unpacked weights
         d.cfg = kCfgStream16;
@@ -249,19 +255,20 @@ int run_igemm(const IgemmDesc &d, hipStream_t st)
     }
     const TileCfg c = kCfg[d.cfg];
     dim3 grid((unsigned)((M + c.bm - 1) / c.bm), d.Npad / c.bn, d.ngroups);
-#define IG_LAUNCH(KC, MW)                                                                           \
+#define IG_LAUNCH(KC, MW, MW64)                                                                     \
     switch (d.cfg) {                                                                               \
     case 0: igemm_f32_kernel<2, 2, 2, 2, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
     case 1: igemm_f32_kernel<3, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
     case 2: igemm_f32_kernel<2, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
     case 3: igemm_f32_kernel<1, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
-    case 4: igemm_f32_kernel<1, 2, 4, 1, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
-    case 5: igemm_f32_kernel<1, 1, 2, 2, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
+    case 4: igemm_f32_kernel<1, 2, 4, 1, KC, MW64, true><<<grid, 256, 0, st>>>(d); break;         \
+    case 5: igemm_f32_kernel<1, 1, 2, 2, KC, MW64, true><<<grid, 256, 0, st>>>(d); break;         \
     case 6: igemm_f32_kernel<2, 1, 4, 1, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
     case 7: igemm_f32_kernel<1, 1, 4, 1, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
     default: igemm_f32_kernel<1, 1, 4, 1, KC, MW, false><<<grid, 256, 0, st>>>(d); break;         \
     }
-    if (igemm_kc(d.K) == 16) { IG_LAUNCH(16, 4) } else { IG_LAUNCH(32, 2) }
+    // minimum blocks per CU (register budget): 64-column tiles keep three blocks resident
+    if (igemm_kc(d.K) == 16) { IG_LAUNCH(16, 3, 3) } else { IG_LAUNCH(32, 2, 3) }
 #undef IG_LAUNCH
     CHECK_LAUNCH("igemm_f32_kernel");
     return 0;

@@ -70,10 +70,9 @@ struct RowInfo {          // per output pixel of the block tile
     int n;
 };
 
-// Main loop: LDS double buffering with one barrier per K-step and global loads two steps ahead of
-// their LDS write.  In step s a wave first writes the tile of step s+1 (in registers since step
-// s-2) into the buffer that was read in step s-1, issues the global loads of step s+3 into the
-// registers just freed, and then runs the MFMAs of step s from the other buffer.
+// Main loop: LDS double buffering with one barrier per K-step.  In step s a wave first writes the
+// tile of step s+1 (loaded into registers during step s-1) into the buffer that was read in step
+// s-1, issues the global loads of step s+2, and then runs the MFMAs of step s from the other buffer.
 template <int WM, int WN, int GM, int GN, int KC, int MINW, bool VEC>
 __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const IgemmDesc d)
 {
@@ -130,23 +129,20 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    // Two register sets: the tile of step k travels through set k & 1, so its global loads have two
-    // whole K-steps to land before they are written to LDS.
     struct Stage {
         f32x4 a[A_PASSES], b[B_PASSES];
-        unsigned amask;          // bit i: pass i holds real data (else it is stored as zero)
     };
-    Stage st0, st1;
+    Stage st0;
+    // The A operand is read through a buffer descriptor: a tap outside the image, a row beyond M
+    // or a padded channel presents an out-of-range offset and loads zero, so every load is issued
+    // unconditionally and its value is used as it is (a branch around a load, or a select behind
+    // it, makes the compiler wait for each load separately and serialises their latencies).
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, (unsigned)d.N * d.in_H * d.in_W * d.in_C * 4u);
 
     auto load_step = [&](int s, Stage &R) {
         const int t = tap0 + s / kchunks;
         const int kc = s % kchunks, kc0 = kc * KC;
         const int dh = taps[t * 2 + 0], dw = taps[t * 2 + 1];
-        // Every load is issued unconditionally (an out-of-image tap or a padded channel reads a
-        // valid dummy address; the value is replaced by zero when it is written to LDS): a branch
-        // around a load, or a select right behind it, makes the compiler wait for each load
-        // separately and serialises their latencies.
-        unsigned am = 0;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
             const int slot = tid + i * NT;
@@ -156,19 +152,15 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
             const int kk = kc0 + ac * 4;
             const bool ok = slot < A_SLOTS && ri.src_base >= 0 && (unsigned)ih < (unsigned)d.in_H &&
                             (unsigned)iw < (unsigned)d.in_W && kk < d.K;
-            const long long off = ok ? ((long long)(ri.src_base + ih * d.in_W + iw) * d.in_C + d.in_coff + kk) : 0;
-            const float *p = d.in + off;
-            f32x4 v;
+            unsigned off = ((unsigned)(ri.src_base + ih * d.in_W + iw) * d.in_C + d.in_coff + kk) * 4u;
+            off |= ok ? 0u : ERF_OOB;
             if (VEC) {
-                v = *reinterpret_cast<const f32x4 *>(p);
+                R.a[i] = buf_load4(r_in, off);
             } else {        // channel counts / alignment that rule out 16-byte loads (rare)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (ok && kk + e < d.K) ? p[e] : 0.0f;
+                for (int e = 0; e < 4; ++e) R.a[i][e] = buf_load1(r_in, (off + 4u * e) | (kk + e < d.K ? 0u : ERF_OOB));
             }
-            R.a[i] = v;
-            am |= (ok ? 1u : 0u) << i;
         }
-        R.amask = am;
         const float *wt = d.wp + ((long long)(t * kchunks + kc) * d.Npad + j0) * KC;
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
@@ -182,10 +174,8 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
         for (int i = 0; i < A_PASSES; ++i) {
             const int slot = tid + i * NT;
             const int r = slot / CPR, ac = slot % CPR;
-            f32x4 v = R.a[i];
-            if (!((R.amask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             if (A_SLOTS % NT == 0 || slot < A_SLOTS)
-                *reinterpret_cast<f32x4 *>(&As[buf][r * KC + (a_swz<KC>(r, ac) << 2)]) = v;
+                *reinterpret_cast<f32x4 *>(&As[buf][r * KC + (a_swz<KC>(r, ac) << 2)]) = R.a[i];
         }
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
@@ -196,11 +186,11 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
     };
 
     // One K-step: write tile s+1 (held in R) to the other LDS buffer, reuse R for the loads of
-    // tile s+3, run the MFMAs of tile s.  One barrier per step.
+    // tile s+2, run the MFMAs of tile s.  One barrier per step.
     auto k_step = [&](int s, Stage &R) {
         const int buf = s & 1;
         if (s + 1 < nsteps) store_step(buf ^ 1, R);
-        if (s + 3 < nsteps) load_step(s + 3, R);
+        if (s + 2 < nsteps) load_step(s + 2, R);
         const int kc0 = (s % kchunks) * KC;
         const float *Ab = As[buf], *Bb = Bs[buf];
 #pragma unroll
@@ -230,13 +220,9 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 
     load_step(0, st0);
     store_step(0, st0);
-    if (nsteps > 1) load_step(1, st1);
-    if (nsteps > 2) load_step(2, st0);
+    if (nsteps > 1) load_step(1, st0);
     __syncthreads();
-    for (int s = 0; s < nsteps; s += 2) {
-        k_step(s, st1);                          // tile s+1 lives in set 1 (s even)
-        if (s + 1 < nsteps) k_step(s + 1, st0);
-    }
+    for (int s = 0; s < nsteps; ++s) k_step(s, st0);
 
     // Epilogue.  C/D layout of the 32x32 MFMA: column = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // All global accesses go through buffer descriptors with 32-bit byte offsets: a row beyond M,
@@ -261,34 +247,38 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
     }
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
-        // rows beyond M carry out_pix = -1: the sign bit, kept as bit 31 of every byte offset,
-        // puts the access out of range (plain bit arithmetic: a select here turns into branches)
-        unsigned opx[16], onn[16], rbad[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const RowInfo ri = rows[row];
-            opx[r] = (unsigned)ri.out_pix;
-            rbad[r] = (unsigned)(ri.out_pix >> 31) & ERF_OOB;
-            onn[r] = (unsigned)ri.n * d.Nout;
-        }
+        for (int hf = 0; hf < 2; ++hf) {      // eight rows at a time keeps the temporaries small
+            // rows beyond M carry out_pix = -1: the sign bit, kept as bit 31 of every byte offset,
+            // puts the access out of range (plain bit arithmetic: a select here turns into branches)
+            unsigned opx[8], onn[8], rbad[8];
 #pragma unroll
-        for (int b = 0; b < WN; ++b) {
-            float rres[16], rmask[16], rns[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const unsigned bad = rbad[r] | cbad[b];
-                rres[r] = buf_load1(r_res, ((opx[r] * d.epi.res_C + d.epi.res_coff + cc[b]) * 4u) | bad);
-                rmask[r] = buf_load1(r_mask, ((opx[r] * d.epi.mask_C + d.epi.mask_coff + cc[b]) * 4u) | bad);
-                rns[r] = buf_load1(r_ns, ((onn[r] + cc[b]) * 4u) | bad);
+            for (int q = 0; q < 8; ++q) {
+                const int r = hf * 8 + q;
+                const int row = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const RowInfo ri = rows[row];
+                opx[q] = (unsigned)ri.out_pix;
+                rbad[q] = (unsigned)(ri.out_pix >> 31) & ERF_OOB;
+                onn[q] = (unsigned)ri.n * d.Nout;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[a][b][r] * sc[b] + sh[b];
-                v = (has_ns ? v * rns[r] : v) + rres[r];
-                if (relu) v = fmaxf(v, 0.0f);
-                v = (!has_mask || rmask[r] > 0.0f) ? v : 0.0f;
-                buf_store1(r_out, ((opx[r] * d.out_C + d.out_coff + cc[b]) * 4u) | rbad[r] | cbad[b], v);
+            for (int b = 0; b < WN; ++b) {
+                float rres[8], rmask[8], rns[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned bad = rbad[q] | cbad[b];
+                    rres[q] = buf_load1(r_res, ((opx[q] * d.epi.res_C + d.epi.res_coff + cc[b]) * 4u) | bad);
+                    rmask[q] = buf_load1(r_mask, ((opx[q] * d.epi.mask_C + d.epi.mask_coff + cc[b]) * 4u) | bad);
+                    rns[q] = buf_load1(r_ns, ((onn[q] + cc[b]) * 4u) | bad);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    float v = acc[a][b][hf * 8 + q] * sc[b] + sh[b];
+                    v = (has_ns ? v * rns[q] : v) + rres[q];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    v = (!has_mask || rmask[q] > 0.0f) ? v : 0.0f;
+                    buf_store1(r_out, ((opx[q] * d.out_C + d.out_coff + cc[b]) * 4u) | rbad[q] | cbad[b], v);
+                }
             }
         }
     }
