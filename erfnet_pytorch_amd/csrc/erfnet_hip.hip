@@ -305,6 +305,8 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
 {
     const long long M = (long long)d.N * d.GH * d.GW;
     if (M >= (1LL << 31)) return fail("wgrad: more than 2^31 pixels");
+    if ((long long)d.N * d.in_H * d.in_W * d.in_C >= (1LL << 29) || (long long)d.N * d.g_H * d.g_W * d.g_C >= (1LL << 29))
+        return fail("wgrad: tensors of 2 GiB or more are not supported");
     d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && d.g_C % 4 == 0 &&
                 d.g_coff % 4 == 0 && d.Nout % 4 == 0 && aligned16(d.in) && aligned16(d.g)) ? 1 : 0;
     if (stream16_enabled() && d.K == 16 && d.Nout == 16 && d.ntaps == 3 && d.ss == 1 && d.os == 1 &&
@@ -340,18 +342,26 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     d.jtiles = (d.Nout + JBLK - 1) / JBLK;
     const int tiles = d.ntaps * d.itiles * d.jtiles;
     const size_t slab = (size_t)d.ntaps * d.K * d.Nout + (size_t)d.ntaps * d.Nout;
-    static int target_blocks = 0;
-    if (!target_blocks) { const char *e = getenv("ERFNET_WGRAD_BLOCKS"); target_blocks = e ? atoi(e) : 768; }
-    long long nsplit = target_blocks / tiles;             // about three blocks per CU
-    if (nsplit < 1) nsplit = 1;
-    const long long max_by_work = (M + 255) / 256;       // at least 8 MFMA k-tiles per block
-    if (nsplit > max_by_work) nsplit = max_by_work;
-    const long long max_by_mem = (long long)((64u << 20) / (slab * sizeof(float)));
-    if (nsplit > max_by_mem) nsplit = max_by_mem;
-    if (nsplit < 1) nsplit = 1;
-    long long sp = (M + nsplit - 1) / nsplit;
-    sp = (sp + 31) / 32 * 32;
-    nsplit = (M + sp - 1) / sp;
+    // Pixels are split in slabs of `spb` 32-pixel steps.  Blocks are dealt round-robin over the
+    // 256 CUs and co-resident blocks share the MFMA pipe, so the kernel lasts as long as the CU
+    // with the most blocks; every slab costs one write and one read of the partial tile.
+    const long long steps = (M + 31) / 32;
+    const double t_step = (IBLK / 64.0) * (JBLK / 64.0) * 0.43;       // us of one block step on a shared pipe
+    const double slab_us = slab * sizeof(float) * 2 / 4.0e6;         // write + read at ~4 TB/s
+    static int forced_spb = -1;
+    if (forced_spb < 0) { const char *e = getenv("ERFNET_WGRAD_SPB"); forced_spb = e ? atoi(e) : 0; }
+    long long best_spb = steps;
+    double best = 1e30;
+    for (long long spb = 2; spb <= steps; ++spb) {
+        const long long ns = (steps + spb - 1) / spb;
+        if (ns * (long long)(slab * sizeof(float)) > (64LL << 20)) continue;
+        const long long per_cu = (tiles * ns + 255) / 256;
+        double t = per_cu * spb * t_step * (per_cu == 1 ? 1.25 : 1.0) + ns * slab_us;
+        if (t < best) { best = t; best_spb = spb; }
+    }
+    if (forced_spb > 0) best_spb = forced_spb < steps ? forced_spb : steps;
+    const long long sp = best_spb * 32;
+    const long long nsplit = (M + sp - 1) / sp;
     d.nsplit = (int)nsplit;
     d.split_pixels = (int)sp;
     d.partial = ar.floats(slab * nsplit);

@@ -121,6 +121,19 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
     const int tap0 = __builtin_amdgcn_readfirstlane(d.gtap0[grp]);
     const int nsteps = __builtin_amdgcn_readfirstlane(d.gntaps[grp]) * kchunks;
 
+    // per-column epilogue constants (channel affine, "column is padding" offset bit), loaded here so
+    // that their latency hides behind the main loop
+    float sc[WN], sh[WN];
+    unsigned cbad[WN], cc[WN];
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+        const int c = j0 + (wn * WN + b) * 32 + l31;
+        const bool cok = c < d.Nout;
+        cc[b] = (unsigned)c;
+        cbad[b] = cok ? 0u : ERF_OOB;
+        epi_channel_affine(d.epi, cok ? c : 0, sc[b], sh[b]);
+    }
+
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int a = 0; a < WM; ++a)
@@ -234,17 +247,6 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
     const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 4u);
     const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, (unsigned)d.N * d.Nout * 4u);
     const bool has_mask = d.epi.mask != nullptr, has_ns = d.epi.nscale != nullptr, relu = d.epi.relu != 0;
-    // per-column constants: channel affine and the "column is padding" offset bit
-    float sc[WN], sh[WN];
-    unsigned cbad[WN], cc[WN];
-#pragma unroll
-    for (int b = 0; b < WN; ++b) {
-        const int c = j0 + (wn * WN + b) * 32 + l31;
-        const bool cok = c < d.Nout;
-        cc[b] = (unsigned)c;
-        cbad[b] = cok ? 0u : ERF_OOB;
-        epi_channel_affine(d.epi, cok ? c : 0, sc[b], sh[b]);
-    }
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
 #pragma unroll
@@ -330,7 +332,6 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
     for (int b = 0; b < JB; ++b) bsum[b] = 0.0f;
 
     f32x4 xreg[XP], greg[GP];
-    unsigned xmask = 0, gmask = 0;
 
     // Pixel table of the step being loaded: the first PM threads each follow one pixel of the
     // 32-pixel window (coordinates advanced incrementally, one division pair in the prologue),
@@ -364,10 +365,10 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
         }
     };
 
+    // operands through buffer descriptors: masked slots load zero (see igemm_f32_kernel)
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, (unsigned)d.N * d.in_H * d.in_W * d.in_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, (unsigned)d.N * d.g_H * d.g_W * d.g_C * 4u);
     auto load_step = [&](int s) {
-        // unconditional loads with a dummy address for masked slots, zeroed at the LDS store
-        // (see igemm_f32_kernel)
-        unsigned xm = 0, gm = 0;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int slot = tid + i * NT;
@@ -376,51 +377,39 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
             const int ih = e.y + dh, iw = e.z + dw;
             const bool ok = slot < XV && e.x >= 0 && i0 + c < d.K && (unsigned)ih < (unsigned)d.in_H &&
                             (unsigned)iw < (unsigned)d.in_W;
-            const long long off = ok ? ((long long)(e.x + ih * d.in_W + iw) * d.in_C + d.in_coff + i0 + c) : 0;
-            const float *px = d.in + off;
-            f32x4 v;
-            if (VEC) v = *reinterpret_cast<const f32x4 *>(px);
+            unsigned off = ((unsigned)(e.x + ih * d.in_W + iw) * d.in_C + d.in_coff + i0 + c) * 4u;
+            off |= ok ? 0u : ERF_OOB;
+            if (VEC) xreg[i] = buf_load4(r_x, off);
             else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (ok && i0 + c + q < d.K) ? px[q] : 0.0f;
+                for (int q = 0; q < 4; ++q) xreg[i][q] = buf_load1(r_x, (off + 4u * q) | (i0 + c + q < d.K ? 0u : ERF_OOB));
             }
-            xreg[i] = v;
-            xm |= (ok ? 1u : 0u) << i;
         }
-        xmask = xm;
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
             const int slot = tid + i * NT;
             const int p = slot / (JBLK / 4), c = (slot % (JBLK / 4)) * 4;
             const int4 e = ptab[s & 1][p < PM ? p : 0];
             const bool ok = slot < GV && e.x >= 0 && j0 + c < d.Nout;
-            const long long off = ok ? ((long long)e.w * d.g_C + d.g_coff + j0 + c) : 0;
-            const float *pg = d.g + off;
-            f32x4 v;
-            if (VEC) v = *reinterpret_cast<const f32x4 *>(pg);
+            unsigned off = ((unsigned)e.w * d.g_C + d.g_coff + j0 + c) * 4u;
+            off |= ok ? 0u : ERF_OOB;
+            if (VEC) greg[i] = buf_load4(r_g, off);
             else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = (ok && j0 + c + q < d.Nout) ? pg[q] : 0.0f;
+                for (int q = 0; q < 4; ++q) greg[i][q] = buf_load1(r_g, (off + 4u * q) | (j0 + c + q < d.Nout ? 0u : ERF_OOB));
             }
-            greg[i] = v;
-            gm |= (ok ? 1u : 0u) << i;
         }
-        gmask = gm;
     };
     auto store_step = [&]() {
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int slot = tid + i * NT;
-            f32x4 v = xreg[i];
-            if (!((xmask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (slot < XV) *reinterpret_cast<f32x4 *>(&Xs[(slot / (IBLK / 4)) * XPITCH + (slot % (IBLK / 4)) * 4]) = v;
+            if (slot < XV) *reinterpret_cast<f32x4 *>(&Xs[(slot / (IBLK / 4)) * XPITCH + (slot % (IBLK / 4)) * 4]) = xreg[i];
         }
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
             const int slot = tid + i * NT;
-            f32x4 v = greg[i];
-            if (!((gmask >> i) & 1u)) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (slot < GV) *reinterpret_cast<f32x4 *>(&Gs[(slot / (JBLK / 4)) * GPITCH + (slot % (JBLK / 4)) * 4]) = v;
+            if (slot < GV) *reinterpret_cast<f32x4 *>(&Gs[(slot / (JBLK / 4)) * GPITCH + (slot % (JBLK / 4)) * 4]) = greg[i];
         }
     };
 
@@ -434,22 +423,29 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc 
         if (s + 1 < nsteps) table_step(s + 1);
         __syncthreads();
         if (s + 1 < nsteps) load_step(s + 1);
-#pragma unroll 4
-        for (int pp = 0; pp < PM / 2; ++pp) {
+        // operand fragments of pixel pair pp+1 are read while the MFMAs of pair pp run
+        float af[2][IB], bf[2][JB];
+        auto read_pair = [&](int pp, int set) {
             const int p = 2 * pp + h;
-            float af[IB], bf[JB];
 #pragma unroll
-            for (int a = 0; a < IB; ++a) af[a] = Xs[p * XPITCH + (wi * IB + a) * 32 + l31];
+            for (int a = 0; a < IB; ++a) af[set][a] = Xs[p * XPITCH + (wi * IB + a) * 32 + l31];
 #pragma unroll
-            for (int b = 0; b < JB; ++b) {
-                bf[b] = Gs[p * GPITCH + (wj * JB + b) * 32 + l31];
-                bsum[b] += bf[b];
-            }
+            for (int b = 0; b < JB; ++b) bf[set][b] = Gs[p * GPITCH + (wj * JB + b) * 32 + l31];
+        };
+        read_pair(0, 0);
+#pragma unroll
+        for (int pp = 0; pp < PM / 2; ++pp) {
+            const int cur = pp & 1;
+            if (pp + 1 < PM / 2) read_pair(pp + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads ahead of this pair's MFMAs
+#pragma unroll
+            for (int b = 0; b < JB; ++b) bsum[b] += bf[cur][b];
 #pragma unroll
             for (int a = 0; a < IB; ++a)
 #pragma unroll
                 for (int b = 0; b < JB; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][a], bf[cur][b], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
