@@ -40,9 +40,6 @@ def parse():
                     choices=["net_classification", "erfnet_bn"],
                     help="net_classification: the fork's training model (BatchNorm off); "
                          "erfnet_bn: eval/erfnet.ERFNet(20) with BatchNorm + Dropout2d in train mode")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="split the per-GPU batch over this many HIP streams (BatchNorm-free model "
-                         "only): independent sub-batches fill each other's launch / ramp bubbles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--forward-only", action="store_true", help="also report forward ms/img only")
     return ap.parse_args()
@@ -162,40 +159,21 @@ def main():
 
     torch.manual_seed(0)
     model = build_model(args.model).to(device).train()
-    reducer = GradientReducer(model)
+    reducer = GradientReducer(model, direct_write=True)
     reducer.broadcast_parameters(0)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
+    # the reference's optimiser settings (train/main.py:43-46,213); `fused` only picks torch's
+    # single-kernel implementation of the same update
+    opt = torch.optim.Adam(params, 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6, fused=True)
     crit = torch.nn.CrossEntropyLoss(ignore_index=-1)
 
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     images = torch.rand(args.batch, 3, HEIGHT, WIDTH, generator=g).to(device)
     labels = torch.randint(-1, CLASSES, (args.batch, HEIGHT, WIDTH), generator=g).to(device)
 
-    nstreams = args.streams if args.model == "net_classification" else 1
-    side = [torch.cuda.Stream(device=device) for _ in range(nstreams - 1)]
-    crit_sum = torch.nn.CrossEntropyLoss(ignore_index=-1, reduction="sum")
-    chunks = [(im, lb) for im, lb in zip(images.chunk(nstreams), labels.chunk(nstreams))]
-    n_valid = (labels != -1).sum().clamp_(min=1).float()
-
     def step():
         reducer.zero_grad()
-        if nstreams == 1:
-            loss = crit(logits_of(model(images)), labels)
-        else:
-            # Sub-batches are independent through the whole network (no BatchNorm), so each runs on
-            # its own stream; the loss is the same mean over all labelled pixels of the batch.
-            main = torch.cuda.current_stream(device)
-            parts = []
-            for i, (im, lb) in enumerate(chunks):
-                st = main if i == 0 else side[i - 1]
-                if st is not main:
-                    st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    parts.append(crit_sum(logits_of(model(im)), lb))
-            for st in side:
-                main.wait_stream(st)
-            loss = torch.stack(parts).sum() / n_valid
+        loss = crit(logits_of(model(images)), labels)
         loss.backward()
         reducer.finish()
         opt.step()
@@ -256,7 +234,7 @@ def main():
                        "model": args.model, "per_gpu_batch": args.batch,
                        "global_batch": world * args.batch,
                        "step": "forward + CrossEntropy(ignore -1) + backward + Adam(lr 1e-4, eps 1e-4, wd 1e-6)",
-                       "parallelism": f"dp{world}", "streams_per_gpu": nstreams,
+                       "parallelism": f"dp{world}",
                        "grad_buckets_bytes": reducer.bucket_sizes},
             "fwd_ms_per_img": round(fwd_ms, 4),
             "final_loss": round(final_loss, 5),

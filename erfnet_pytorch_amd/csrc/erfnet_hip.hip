@@ -36,7 +36,9 @@ int fail(const char *fmt, ...)
 // beside the data-gradient chain and fill the launch / write-back gaps of its kernels).  One low
 // priority stream and a few events per host thread and device, created on first use; every call
 // that forks work onto it joins it back into the caller's stream before returning, so from the
-// caller's side all work is ordered on the stream it passed.  ERFNET_NO_SIDE_STREAM=1 disables it.
+// caller's side all work is ordered on the stream it passed.  Off by default (measured neutral on
+// the whole training step: the data-gradient kernels leave too little LDS for a second resident
+// kernel); ERFNET_SIDE_STREAM=1 turns it on.
 struct Side {
     hipStream_t s = nullptr;
     hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join = nullptr;
@@ -47,7 +49,7 @@ thread_local Side g_side[32];
 Side *side_stream()
 {
     static int enabled = -1;
-    if (enabled < 0) { const char *e = getenv("ERFNET_NO_SIDE_STREAM"); enabled = (e && atoi(e)) ? 0 : 1; }
+    if (enabled < 0) { const char *e = getenv("ERFNET_SIDE_STREAM"); enabled = (e && atoi(e)) ? 1 : 0; }
     if (!enabled) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;

@@ -14,6 +14,11 @@ Design points
     ``encoder.output_conv.*``, ``class_power``) are found on the first backward pass and left out of
     later steps instead of forcing ``find_unused_parameters``.
   * BatchNorm statistics stay per replica and dropout masks per rank, as under DataParallel.
+  * With ``direct_write`` the block kernels write each weight gradient straight into its bucket
+    slice (functional._grad_targets): no temporary, no accumulation kernel per parameter.  A
+    parameter's buffer is granted once per step, so a second gradient of the same parameter
+    (weight sharing) still accumulates through autograd; gradients therefore do NOT accumulate
+    across several backward passes without ``zero_grad`` in between when this is on.
   * The payload is small (8.2 MB of fp32 for the 20-class network), i.e. latency-bound on xGMI:
     few, large buckets beat many small ones.
 """
@@ -24,8 +29,10 @@ import torch.distributed as dist
 class GradientReducer:
     """Bucketed, overlapped gradient averaging for a replicated module."""
 
-    def __init__(self, module, bucket_bytes=4 << 20, process_group=None):
+    def __init__(self, module, bucket_bytes=4 << 20, process_group=None, direct_write=False):
         self.module = module
+        self._direct = bool(direct_write)
+        self._written = set()
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -71,6 +78,8 @@ class GradientReducer:
             if p.grad is not None:
                 view.copy_(p.grad)
             p.grad = view
+            if self._direct:
+                p._erf_grad_sink = (view, self)
             off += p.numel()
             self._bucket_of[p] = len(self._buckets)
         self._buckets.append((flat, list(params)))
@@ -83,6 +92,17 @@ class GradientReducer:
         self._pending = {i: len(ps) for i, (_, ps) in enumerate(self._buckets)}
         self._work = []
         self._seen = set()
+        self._written = set()
+
+    # direct gradient write (see functional._grad_targets)
+    def _claim(self, p):
+        if not self._first_step_done or p in self._written or p not in self._bucket_of:
+            return False
+        self._written.add(p)
+        return True
+
+    def _delivered(self, p):
+        self._on_grad(p)
 
     def _on_grad(self, p):
         if self.world == 1 and self._first_step_done:
@@ -112,6 +132,8 @@ class GradientReducer:
             grads = {p: p.grad.clone() for p in active}
             for p in stale:
                 p.grad = None
+                if hasattr(p, "_erf_grad_sink"):
+                    del p._erf_grad_sink
             for p in active:
                 p.grad = grads[p]
             self._build_buckets(active)
@@ -137,3 +159,6 @@ class GradientReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            if hasattr(p, "_erf_grad_sink"):
+                del p._erf_grad_sink

@@ -95,6 +95,40 @@ def _arr(ts):
     return (vp * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
 
 
+# Direct gradient write.  An owner of the parameters (ddp.GradientReducer) may attach
+# ``_erf_grad_sink = (buffer, owner)`` to a Parameter: backward then lets the weight-gradient kernel
+# write straight into ``buffer`` (the parameter's slice of a flat bucket) and returns None to
+# autograd, which saves the temporary and autograd's accumulation kernel.  The owner grants the
+# buffer once per step (``_claim``); any further gradient of the same parameter in that step takes
+# the ordinary accumulate path.  ``_delivered`` tells the owner the write has been enqueued.
+def _grad_targets(params, shapes, device):
+    """[(tensor the kernel writes, parameter if it is the owner's buffer else None)]; a None shape
+    gives (None, None)."""
+    out = []
+    for q, shape in zip(params, shapes):
+        if shape is None:
+            out.append((None, None))
+            continue
+        sink = getattr(q, "_erf_grad_sink", None) if q is not None else None
+        if sink is not None and tuple(sink[0].shape) == tuple(shape) and sink[1]._claim(q):
+            out.append((sink[0], q))
+        else:
+            out.append((torch.empty(tuple(shape), dtype=torch.float32, device=device), None))
+    return out
+
+
+def _deliver(targets):
+    """Values handed to autograd: None where the kernel wrote into the owner's buffer."""
+    res = []
+    for buf, q in targets:
+        if q is not None:
+            q._erf_grad_sink[1]._delivered(q)
+            res.append(None)
+        else:
+            res.append(buf)
+    return res
+
+
 # ------------------------------------------------------------------------------ DownsamplerBlock
 class _Downsampler(torch.autograd.Function):
     @staticmethod
@@ -123,6 +157,7 @@ class _Downsampler(torch.autograd.Function):
         if need:
             ctx.save_for_backward(x, wq, y, pre, bn.gamma, bn.save_mean, bn.save_invstd)
             ctx.cfg = (mode, momentum, eps)
+            ctx.params = (w, b, gamma, beta)
         return y
 
     @staticmethod
@@ -136,10 +171,9 @@ class _Downsampler(torch.autograd.Function):
         bn = _Bn(mode, gamma, None, None, None, momentum, eps, False, saved=(smean, sinv))
         need_dx = ctx.needs_input_grad[0]
         dx = _empty_nhwc(n, cin, h, wd, x) if need_dx else None
-        dw = torch.empty_like(wq)
-        db = torch.empty(wq.shape[0], dtype=torch.float32, device=x.device)
-        dg = torch.empty(cout, dtype=torch.float32, device=x.device) if mode else None
-        dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if mode else None
+        cvec = (cout,) if mode else None
+        tg = _grad_targets(ctx.params, (wq.shape, (wq.shape[0],), cvec, cvec), x.device)
+        dw, db, dg, dbt = (t[0] for t in tg)
         ws = _workspace(x, n * (h // 2) * (wd // 2), cout)
         sn, sc, sh, sw = x.stride()
         with _dev_ctx(x):
@@ -147,6 +181,7 @@ class _Downsampler(torch.autograd.Function):
                                                     _p(pre), _p(gy), _p(dx), _p(dw), _p(db), _p(dg),
                                                     _p(dbt), n, cin, h, wd, cout, _p(ws), ws.numel(),
                                                     _stream(x)))
+        dw, db, dg, dbt = _deliver(tg)
         return dx, dw, db, dg, dbt, None, None, None, None, None
 
 
@@ -187,6 +222,7 @@ class _Nb1d(torch.autograd.Function):
             ctx.save_for_backward(x, y, *save, *ws_, bn1.gamma, bn2.gamma, bn1.save_mean,
                                   bn1.save_invstd, bn2.save_mean, bn2.save_invstd, ds)
             ctx.cfg = (int(dil), mode, momentum, eps)
+            ctx.params = (w0, b0, w1, b1, w2, b2, w3, b3, g1, be1, g2, be2)
         return y
 
     @staticmethod
@@ -199,21 +235,19 @@ class _Nb1d(torch.autograd.Function):
         bn1 = _Bn(mode, g1, None, None, None, momentum, eps, False, saved=(sm1, si1))
         bn2 = _Bn(mode, g2, None, None, None, momentum, eps, False, saved=(sm2, si2))
         dx = torch.empty_like(x)
-        dws = [torch.empty_like(w) for w in (w0, w1, w2, w3)]
-        dbs = [torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(4)]
-        if mode:
-            dgs = [torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(2)]
-            dbts = [torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(2)]
-        else:
-            dgs = dbts = [None, None]
+        cvec = (c,) if mode else None
+        tg = _grad_targets(ctx.params, (w0.shape, (c,), w1.shape, (c,), w2.shape, (c,), w3.shape, (c,),
+                                        cvec, cvec, cvec, cvec), x.device)
+        dws = [tg[i][0] for i in (0, 2, 4, 6)]
+        dbs = [tg[i][0] for i in (1, 3, 5, 7)]
+        dgs, dbts = [tg[8][0], tg[10][0]], [tg[9][0], tg[11][0]]
         ws = _workspace(x, n * h * wd, c)
         with _dev_ctx(x):
             _lib.check(lib.erf_nb1d_backward(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
                                              dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
                                              _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
                                              _p(ws), ws.numel(), _stream(x)))
-        return (dx, dws[0], dbs[0], dws[1], dbs[1], dws[2], dbs[2], dws[3], dbs[3],
-                dgs[0], dbts[0], dgs[1], dbts[1], None, None, None, None, None, None, None, None, None)
+        return (dx, *_deliver(tg), None, None, None, None, None, None, None, None, None)
 
 
 def nb1d(x, weights, biases, dilated, bn1=None, bn2=None, bn_mode=0, drop_scale=None, momentum=0.1,
@@ -253,6 +287,7 @@ class _Upsampler(torch.autograd.Function):
         if need:
             ctx.save_for_backward(x, wq, y, pre, bn.gamma, bn.save_mean, bn.save_invstd)
             ctx.cfg = (mode, momentum, eps)
+            ctx.params = (w, b, gamma, beta)
         return y
 
     @staticmethod
@@ -265,15 +300,15 @@ class _Upsampler(torch.autograd.Function):
         gy = _nhwc(gy)
         bn = _Bn(mode, gamma, None, None, None, momentum, eps, False, saved=(smean, sinv))
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(wq)
-        db = torch.empty(cout, dtype=torch.float32, device=x.device)
-        dg = torch.empty(cout, dtype=torch.float32, device=x.device) if mode else None
-        dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if mode else None
+        cvec = (cout,) if mode else None
+        tg = _grad_targets(ctx.params, (wq.shape, (cout,), cvec, cvec), x.device)
+        dw, db, dg, dbt = (t[0] for t in tg)
         ws = _workspace(x, n * 4 * h * wd, max(cin, cout))
         with _dev_ctx(x):
             _lib.check(lib.erf_upsampler_backward(_p(x), _p(wq), bn.ref(), _p(y), _p(pre), _p(gy), _p(dx),
                                                   _p(dw), _p(db), _p(dg), _p(dbt), n, cin, h, wd, cout,
                                                   _p(ws), ws.numel(), _stream(x)))
+        dw, db, dg, dbt = _deliver(tg)
         return dx, dw, db, dg, dbt, None, None, None, None, None
 
 
@@ -300,6 +335,7 @@ class _OutConv(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, wq)
             ctx.has_bias = b is not None
+            ctx.params = (w, b)
         return y
 
     @staticmethod
@@ -312,12 +348,13 @@ class _OutConv(torch.autograd.Function):
         if gy.dtype != torch.float32:
             raise TypeError("erfnet_hip kernels compute in fp32")
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(wq)
-        db = torch.empty(ncls, dtype=torch.float32, device=x.device)
+        tg = _grad_targets(ctx.params, (wq.shape, (ncls,)), x.device)
+        dw, db = tg[0][0], tg[1][0]
         ws = _workspace(x, n * h * wd, 16)
         with _dev_ctx(x):
             _lib.check(lib.erf_outconv_backward(_p(x), _p(wq), _p(gy), _p(dx), _p(dw), _p(db), n, cin, h,
                                                 wd, ncls, _p(ws), ws.numel(), _stream(x)))
+        dw, db = _deliver(tg)
         return dx, dw, (db if ctx.has_bias else None)
 
 
@@ -359,6 +396,7 @@ class _Conv2d(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, wq, y if relu else None)
             ctx.cfg = (k, int(relu), b is not None)
+            ctx.params = (w, b)
         return y
 
     @staticmethod
@@ -370,12 +408,13 @@ class _Conv2d(torch.autograd.Function):
         cout = wq.shape[0]
         gy = _nhwc(gy)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(wq)
-        db = torch.empty(cout, dtype=torch.float32, device=x.device)
+        tg = _grad_targets(ctx.params, (wq.shape, (cout,)), x.device)
+        dw, db = tg[0][0], tg[1][0]
         ws = _workspace(x, n * h * wd, max(cin, cout))
         with _dev_ctx(x):
             _lib.check(lib.erf_conv2d_backward(_p(x), _p(wq), _p(y), _p(gy), _p(dx), _p(dw), _p(db), n, cin,
                                                h, wd, cout, k, relu, _p(ws), ws.numel(), _stream(x)))
+        dw, db = _deliver(tg)
         return dx, dw, (db if has_bias else None), None
 
 

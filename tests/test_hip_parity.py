@@ -316,6 +316,42 @@ def test_two_adam_steps_match_reference():
         assert abs(float(pd.abs().sum()) - a) <= 2e-4 * max(1.0, a) + 1e-5, k
 
 
+def test_direct_gradient_write_matches_autograd_accumulation():
+    """GradientReducer(direct_write=True) lets the kernels write each weight gradient into its
+    bucket slice; the values must equal what autograd's accumulation leaves there, step after
+    step, and the reference's two-step training numbers must still come out."""
+    from erfnet_pytorch_amd.ddp import GradientReducer
+    ref = gu.load_json("trainstep.json")
+    x = t(gu.det_uniform("trainstep.x", (2, 3, 64, 128), 0.0, 1.0))
+    lab = t(gu.det_labels("trainstep.lab", (2, 64, 128), -1, 20))
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    grads = {}
+    for direct in (False, True):
+        net = gu.fill_state_dict(make_model("net_classification_20"), tag="trainstep").to(DEV).train()
+        red = GradientReducer(net, direct_write=direct)
+        opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], 1e-4, (0.9, 0.999),
+                               eps=1e-4, weight_decay=1e-6)
+        per_step = []
+        for step in range(3):
+            red.zero_grad()
+            out, _ = net(x)
+            loss = crit(out, lab)
+            loss.backward()
+            red.finish()
+            per_step.append({k: p.grad.detach().clone() for k, p in net.named_parameters()
+                             if p.grad is not None})
+            opt.step()
+            if step < 2:
+                assert abs(loss.item() - ref["losses"][step]) < 1e-3
+        grads[direct] = per_step
+        red.remove()
+    for step in range(3):
+        a, b = grads[False][step], grads[True][step]
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (step, k)
+
+
 # ------------------------------------------------------------- full benchmark size: properties
 def _torch_nb1d(x, ws, bs, d):
     import torch.nn.functional as F
