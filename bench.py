@@ -125,7 +125,8 @@ def cpu_baseline():
     model.train()
     torch.set_num_threads(cores)
     xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
-    crit = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
+    crit = CrossEntropyLoss2d()       # train/main.py:186-188
     with torch.no_grad():
         model(xt)
         t0 = time.perf_counter()
@@ -165,7 +166,8 @@ def main():
     # the reference's optimiser settings (train/main.py:43-46,213); `fused` only picks torch's
     # single-kernel implementation of the same update
     opt = torch.optim.Adam(params, 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6, fused=True)
-    crit = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
+    crit = CrossEntropyLoss2d()       # train/main.py:186-188
 
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     images = torch.rand(args.batch, 3, HEIGHT, WIDTH, generator=g).to(device)

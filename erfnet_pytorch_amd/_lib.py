@@ -84,6 +84,10 @@ _PROTOS = {
                                      C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_conv2d_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "erf_cross_entropy_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ll, vp,
+                                            C.c_size_t, vp]),
+    "erf_cross_entropy_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, ll, vp]),
 }
 
 EXPORTS = tuple(_PROTOS)

@@ -4,6 +4,7 @@
 #include "aux_kernels.h"
 #include "igemm.h"
 #include "stream16.h"
+#include "loss_kernels.h"
 
 #include <atomic>
 #include <cstdarg>
@@ -1051,6 +1052,42 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
         if (launch_igemm(d, ar, st)) return 1;
     }
     return side_join(sd, st);
+}
+
+// ================================================================================ CrossEntropyLoss2d
+int erf_cross_entropy_forward(const float *logits, const long long *target, float *stats, float *lse,
+                              int N, int K, int H, int W, long long ignore_index, void *ws,
+                              size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (K < 1) return fail("cross entropy: no classes");
+    const long long P = (long long)N * H * W;
+    if (P == 0) return fail("cross entropy: empty input");
+    const long long blocks = (P + CE_BLOCK - 1) / CE_BLOCK;
+    if (blocks >= (1LL << 31)) return fail("cross entropy: too many pixels");
+    float *partial = ar.floats((size_t)blocks * 2);
+    if (!partial) return fail("cross entropy: workspace too small");
+    CeDesc d = {logits, target, lse, partial, P, H * W, K, ignore_index};
+    ce_fwd_kernel<<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
+    CHECK_LAUNCH("ce_fwd_kernel");
+    ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
+    CHECK_LAUNCH("ce_reduce_kernel");
+    return 0;
+}
+
+int erf_cross_entropy_backward(const float *logits, const long long *target, const float *lse,
+                               const float *stats, const float *gy, float *dlogits, int N, int K, int H,
+                               int W, long long ignore_index, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const long long P = (long long)N * H * W;
+    if (P == 0 || K < 1) return fail("cross entropy: empty input");
+    const long long blocks = (P + CE_BLOCK - 1) / CE_BLOCK;
+    CeBwdDesc d = {logits, target, lse, stats, gy, dlogits, P, H * W, K, ignore_index};
+    ce_bwd_kernel<<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
+    CHECK_LAUNCH("ce_bwd_kernel");
+    return 0;
 }
 
 }  // extern "C"

@@ -422,3 +422,48 @@ def conv2d(x, w, b, relu=False):
     """nn.Conv2d with a 1x1 or 3x3 kernel, stride 1, 'same' padding (Encoder.output_conv,
     eval/erfnet.py:85; LadderBlock.conv, train/erfnet_blocks.py:145), optionally fused with ReLU."""
     return _Conv2d.apply(x, w, b, relu)
+
+
+# ------------------------------------------------------------------------------ CrossEntropyLoss2d
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        lib = _lib.lib()
+        if logits.dtype != torch.float32:
+            raise TypeError(f"erfnet_hip kernels compute in fp32, got {logits.dtype}")
+        if target.dtype != torch.int64:
+            raise TypeError(f"cross_entropy: target must be int64 class indices, got {target.dtype}")
+        n, k, h, wd = logits.shape
+        if tuple(target.shape) != (n, h, wd):
+            raise ValueError(f"cross_entropy: target shape {tuple(target.shape)} does not match logits "
+                             f"{tuple(logits.shape)}")
+        x = logits.contiguous()
+        tg = target.contiguous()
+        stats = torch.empty(2, dtype=torch.float32, device=x.device)
+        lse = torch.empty((n, h, wd), dtype=torch.float32, device=x.device)
+        ws = _workspace(x, n * h * wd, 1)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_cross_entropy_forward(_p(x), _p(tg), _p(stats), _p(lse), n, k, h, wd,
+                                                     int(ignore_index), _p(ws), ws.numel(), _stream(x)))
+        if ctx.needs_input_grad[0]:
+            ctx.save_for_backward(x, tg, lse, stats)
+            ctx.ignore_index = int(ignore_index)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        x, tg, lse, stats = ctx.saved_tensors
+        n, k, h, wd = x.shape
+        gy = gy.to(torch.float32).reshape(1).contiguous()
+        dx = torch.empty_like(x)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_cross_entropy_backward(_p(x), _p(tg), _p(lse), _p(stats), _p(gy), _p(dx),
+                                                      n, k, h, wd, ctx.ignore_index, _stream(x)))
+        return dx, None, None
+
+
+def cross_entropy(logits, target, ignore_index=-1):
+    """nn.CrossEntropyLoss(ignore_index)(logits, target) for [N,K,H,W] logits and [N,H,W] int64
+    targets (the reference's CrossEntropyLoss2d, train/evaluation_functions.py:6-14) on the GPU."""
+    return _CrossEntropy.apply(logits, target, ignore_index)

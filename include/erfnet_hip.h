@@ -128,6 +128,20 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
                         float *dx, float *dw, float *db, int N, int Cin, int H, int W, int Cout,
                         int k, int relu, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- CrossEntropyLoss2d = nn.CrossEntropyLoss(ignore_index=-1)
+ *      (train/evaluation_functions.py:6-14; used by train/main.py:186-188,333,373) -------------
+ * logits NCHW-contiguous [N,K,H,W] fp32 (what erf_outconv_forward writes); target [N,H,W] int64 with
+ * values in [0,K) or ignore_index.  stats[2] (device) receives {mean of -log softmax[target] over
+ * the labelled pixels, number of labelled pixels}; lse [N,H,W] receives the per-pixel log-sum-exp
+ * that backward reuses.  No pixel labelled -> stats[0] is NaN, as in torch. */
+int erf_cross_entropy_forward(const float *logits, const long long *target, float *stats, float *lse,
+                              int N, int K, int H, int W, long long ignore_index, void *ws,
+                              size_t ws_bytes, void *stream);
+/* dlogits = d(stats[0])/d(logits) * gy[0]; gy is a device scalar (the upstream gradient). */
+int erf_cross_entropy_backward(const float *logits, const long long *target, const float *lse,
+                               const float *stats, const float *gy, float *dlogits, int N, int K, int H,
+                               int W, long long ignore_index, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

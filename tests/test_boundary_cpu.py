@@ -151,3 +151,16 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".h", ".hip")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("test infrastructure", ""), f
+
+
+def test_cross_entropy_loss2d_cpu_matches_torch():
+    """CrossEntropyLoss2d keeps the reference's signature (weight accepted and ignored,
+    train/evaluation_functions.py:8-11) and its CPU path is torch's own op."""
+    import torch
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 6, 7, generator=g)
+    lab = torch.randint(-1, 5, (2, 6, 7), generator=g)
+    a = CrossEntropyLoss2d(weight=torch.ones(5))(x, lab)
+    b = torch.nn.functional.cross_entropy(x, lab, ignore_index=-1)
+    assert torch.equal(a, b)

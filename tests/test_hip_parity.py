@@ -299,7 +299,8 @@ def test_two_adam_steps_match_reference():
     ref = gu.load_json("trainstep.json")
     net = gu.fill_state_dict(make_model("net_classification_20"), tag="trainstep").to(DEV).train()
     opt = torch.optim.Adam(net.parameters(), 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
-    crit = torch.nn.CrossEntropyLoss(ignore_index=-1)
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
+    crit = CrossEntropyLoss2d()
     x = t(gu.det_uniform("trainstep.x", (2, 3, 64, 128), 0.0, 1.0))
     lab = t(gu.det_labels("trainstep.lab", (2, 64, 128), -1, 20))
     for step in range(2):
@@ -350,6 +351,39 @@ def test_direct_gradient_write_matches_autograd_accumulation():
         assert a.keys() == b.keys()
         for k in a:
             assert torch.equal(a[k], b[k]), (step, k)
+
+
+@pytest.mark.parametrize("shape,k", [((2, 64, 128), 20), ((1, 7, 13), 1), ((3, 33, 17), 5)])
+def test_cross_entropy_against_torch_and_oracle(shape, k):
+    """CrossEntropyLoss2d (train/evaluation_functions.py:6-14): loss and gradient of the HIP kernels
+    against the oracle's float64 restatement and torch's own op on the same tensors."""
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
+    from oracle import oracle as orc
+    n, h, w = shape
+    x_np = (gu.det_normal(f"ce.x.{k}", (n, k, h, w)) * 3.0).astype(np.float32)
+    lab_np = gu.det_labels(f"ce.lab.{k}", (n, h, w), -1, k)
+    x = t(x_np).requires_grad_(True)
+    lab = t(lab_np)
+    n0 = launches()
+    loss = CrossEntropyLoss2d()(x, lab)
+    (loss * 1.7).backward()
+    assert launches() > n0
+    ref_loss, ref_g = orc._ce_loss_and_grad(x_np, lab_np)
+    assert abs(loss.item() - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), 1.7 * ref_g, rtol=2e-5, atol=1e-9)
+    x2 = t(x_np).requires_grad_(True)
+    l2 = torch.nn.functional.cross_entropy(x2, lab, ignore_index=-1)
+    (l2 * 1.7).backward()
+    assert abs(loss.item() - l2.item()) <= 1e-5 * max(1.0, abs(l2.item()))
+    assert torch.allclose(x.grad, x2.grad, rtol=2e-5, atol=1e-9)
+
+
+def test_cross_entropy_nothing_labelled_is_nan():
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
+    x = t(gu.det_normal("ce.x.nan", (1, 4, 8, 8)))
+    lab = torch.full((1, 8, 8), -1, dtype=torch.int64, device=DEV)
+    assert torch.isnan(CrossEntropyLoss2d()(x, lab))
+    assert torch.isnan(torch.nn.functional.cross_entropy(x, lab, ignore_index=-1))
 
 
 # ------------------------------------------------------------- full benchmark size: properties
