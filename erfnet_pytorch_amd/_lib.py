@@ -63,23 +63,23 @@ _PROTOS = {
                                           C.c_size_t, vp]),
     "erf_downsampler_backward": (C.c_int, [vp, ll, ll, ll, ll, vp, C.POINTER(BnStruct), vp, vp, vp,
                                            vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                           C.c_int, vp, C.c_size_t, vp]),
+                                           C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_nb1d_forward": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(BnStruct),
                                    C.POINTER(BnStruct), vp, C.c_int, vp, C.POINTER(vp), C.c_int,
                                    C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_nb1d_backward": (C.c_int, [vp, C.POINTER(vp), C.POINTER(BnStruct), C.POINTER(BnStruct), vp,
                                     C.c_int, vp, C.POINTER(vp), vp, vp, C.POINTER(vp),
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,
-                                    C.c_int, C.c_int, vp, C.c_size_t, vp]),
+                                    C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_upsampler_forward": (C.c_int, [vp, vp, vp, C.POINTER(BnStruct), vp, vp, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_upsampler_backward": (C.c_int, [vp, vp, C.POINTER(BnStruct), vp, vp, vp, vp, vp, vp, vp, vp,
-                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
                                          C.c_size_t, vp]),
     "erf_outconv_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, vp]),
     "erf_outconv_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
-                                       C.c_int, vp, C.c_size_t, vp]),
+                                       C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_conv2d_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_conv2d_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
@@ -89,6 +89,8 @@ _PROTOS = {
     "erf_cross_entropy_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                              C.c_int, ll, vp]),
 }
+
+BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
 
 EXPORTS = tuple(_PROTOS)
 

@@ -492,6 +492,7 @@ struct OutConvBwdDesc {
     const float *x, *w, *gy;
     float *dx, *partial;
     int N, H, W, ncls, split_pixels;
+    int mask_dx;
 };
 
 __global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc d)
@@ -525,6 +526,11 @@ __global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc
 #pragma unroll
     for (int q = 0; q < OC_CIN / 4; ++q) {
         f32x4 v = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+        if (d.mask_dx) {          // gradient handed to a ReLU-ended producer, masked here by x > 0
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(d.x + m * OC_CIN + q * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = xv[e] > 0.0f ? v[e] : 0.0f;
+        }
         *reinterpret_cast<f32x4 *>(d.dx + m * OC_CIN + q * 4) = v;
     }
 }

@@ -613,22 +613,28 @@ int erf_downsampler_forward(const float *x, long long sn, long long sc, long lon
 int erf_downsampler_backward(const float *x, long long sn, long long sc, long long sh, long long sw,
                              const float *w, const erf_bn_t *bn, const float *y, const float *pre,
                              const float *gy, float *dx, float *dw, float *db, float *dgamma,
-                             float *dbeta, int N, int Cin, int H, int W, int Cout, void *ws,
-                             size_t ws_bytes, void *stream)
+                             float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
+                             void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     const int Cc = Cout - Cin, Ho = H / 2, Wo = W / 2;
     const long long Mo = (long long)N * Ho * Wo;
     const int mode = bn_mode(bn);
-    float *g = ar.floats((size_t)Mo * Cout);
-    if (!g) return fail("DownsamplerBlock backward: workspace too small");
-    Side *sd = nullptr;
-    if (mode) {
-        if (bn_backward(bn, pre, gy, y, nullptr, g, dgamma, dbeta, Mo, Cout, Ho * Wo, ar, st)) return 1;
-    } else {
-        if (launch_mask(gy, y, g, Mo, Cout, st)) return 1;
+    const bool premasked = (flags & ERF_BWD_GY_PREMASKED) != 0;
+    const float *g = gy;
+    if (mode || !premasked) {
+        float *gbuf = ar.floats((size_t)Mo * Cout);
+        if (!gbuf) return fail("DownsamplerBlock backward: workspace too small");
+        if (mode) {
+            if (bn_backward(bn, pre, gy, premasked ? nullptr : y, nullptr, gbuf, dgamma, dbeta, Mo, Cout,
+                            Ho * Wo, ar, st)) return 1;
+        } else {
+            if (launch_mask(gy, y, gbuf, Mo, Cout, st)) return 1;
+        }
+        g = gbuf;
     }
+    Side *sd = nullptr;
     if (Cin == 3) {
         const int nw = Cc * 27;
         long long nsplit = (Mo + 2047) / 2048;
@@ -668,6 +674,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         zero_desc(d);
         d.in = g; d.w = w; d.out = dx;
         d.epi.res = dx; d.epi.res_C = Cin; d.epi.res_coff = 0;
+        if (flags & ERF_BWD_MASK_DX) { d.epi.mask = x; d.epi.mask_C = Cin; }
         d.N = N; d.GH = Ho; d.GW = Wo;
         d.in_H = Ho; d.in_W = Wo; d.in_C = Cout; d.in_coff = 0; d.K = Cc; d.ss = 1;
         d.out_H = H; d.out_W = W; d.out_C = Cin; d.Nout = Cin; d.os = 2;
@@ -763,8 +770,8 @@ int erf_nb1d_forward(const float *x, const float *const w[4], const float *const
 int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
                       const float *drop_scale, int dil, const float *y, const float *const save[5],
                       const float *gy, float *dx, float *const dw[4], float *const db[4],
-                      float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, void *ws,
-                      size_t ws_bytes, void *stream)
+                      float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, int flags,
+                      void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
@@ -777,10 +784,16 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     // Every tensor of the gradient chain gets a buffer of its own, so the weight gradients (helper
     // stream) can read them while the chain moves on:
     //   g4 = gy*(y>0) -> [gs = bn2'/dropout'(g4)] -> gb -> ga -> [gn = bn1'(ga)] -> g1 -> dx
-    float *g4 = ar.floats(nel), *ga = ar.floats(nel), *gb = ar.floats(nel), *g1 = ar.floats(nel);
-    float *gs = (m2 || drop_scale) ? ar.floats(nel) : g4;
-    float *gn = m1 ? ar.floats(nel) : ga;
-    if (!g4 || !ga || !gb || !g1 || !gs || !gn) return fail("non_bottleneck_1d backward: workspace too small");
+    const bool premasked = (flags & ERF_BWD_GY_PREMASKED) != 0;
+    float *g4buf = premasked ? nullptr : ar.floats(nel);
+    const float *g4 = premasked ? gy : g4buf;
+    float *ga = ar.floats(nel), *gb = ar.floats(nel), *g1 = ar.floats(nel);
+    float *gsbuf = (m2 || drop_scale) ? ar.floats(nel) : nullptr;
+    const float *gs = gsbuf ? gsbuf : g4;
+    float *gnbuf = m1 ? ar.floats(nel) : nullptr;
+    const float *gn = gnbuf ? gnbuf : ga;
+    if ((!premasked && !g4buf) || !ga || !gb || !g1 || ((m2 || drop_scale) && !gsbuf) || (m1 && !gnbuf))
+        return fail("non_bottleneck_1d backward: workspace too small");
     const int woff[3] = {0, 1, 2};
     WgradDesc wd;
 
@@ -794,6 +807,7 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     d[1].epi.mask = t1; d[1].epi.mask_C = C;
     conv1d_desc(d[0], g1, w[0], dx, N, C, H, W, 0, 1, true);        // + g4 (residual path)
     d[0].epi.res = g4; d[0].epi.res_C = C;
+    if (flags & ERF_BWD_MASK_DX) { d[0].epi.mask = x; d[0].epi.mask_C = C; }
     for (int i = 0; i < 4; ++i)
         if (plan_igemm(d[i], ar, pk[i])) return 1;
     if (launch_pack(pk, 4, st)) return 1;
@@ -807,14 +821,14 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     Side *sd = side_stream();
 
     // g4 = gy * (y > 0): gradient of the residual sum (goes to x unchanged and into the conv branch)
-    if (launch_mask(gy, y, g4, M, C, st)) return 1;
+    if (!premasked && launch_mask(gy, y, g4buf, M, C, st)) return 1;
     if (m2) {
-        if (bn_backward(bn2, p4, g4, nullptr, drop_scale, gs, dgamma ? dgamma[1] : nullptr,
+        if (bn_backward(bn2, p4, g4, nullptr, drop_scale, gsbuf, dgamma ? dgamma[1] : nullptr,
                         dbeta ? dbeta[1] : nullptr, M, C, H * W, bn_ar, st)) return 1;
     } else if (drop_scale) {
         Epilogue e = kNoEpi;
         e.nscale = drop_scale;
-        if (launch_elt(g4, gs, e, M, C, H * W, st)) return 1;
+        if (launch_elt(g4, gsbuf, e, M, C, H * W, st)) return 1;
     }
     // conv1x3_2: weight gradient from (t3, gs); data gradient -> gb
     hipStream_t ss = side_fork(sd, 0, st);
@@ -829,7 +843,7 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     if (launch_wgrad(wd, dw[2], db[2], woff, 3, C * 3, 1u, ar, ss)) return 1;
     if (run_igemm(d[2], st)) return 1;
     if (m1) {
-        if (bn_backward(bn1, p2, ga, nullptr, nullptr, gn, dgamma ? dgamma[0] : nullptr,
+        if (bn_backward(bn1, p2, ga, nullptr, nullptr, gnbuf, dgamma ? dgamma[0] : nullptr,
                         dbeta ? dbeta[0] : nullptr, M, C, H * W, bn_ar, st)) return 1;
     }
     // conv1x3_1: (t1, gn) -> g1
@@ -893,19 +907,25 @@ int erf_upsampler_forward(const float *x, const float *w, const float *b, const 
 
 int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, const float *y,
                            const float *pre, const float *gy, float *dx, float *dw, float *db,
-                           float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout, void *ws,
-                           size_t ws_bytes, void *stream)
+                           float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
+                           void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     const int mode = bn_mode(bn);
     const long long Mo = (long long)N * 4 * H * W;
-    float *g = ar.floats((size_t)Mo * Cout);
-    if (!g) return fail("UpsamplerBlock backward: workspace too small");
-    if (mode) {
-        if (bn_backward(bn, pre, gy, y, nullptr, g, dgamma, dbeta, Mo, Cout, 4 * H * W, ar, st)) return 1;
-    } else {
-        if (launch_mask(gy, y, g, Mo, Cout, st)) return 1;
+    const bool premasked = (flags & ERF_BWD_GY_PREMASKED) != 0;
+    const float *g = gy;
+    if (mode || !premasked) {
+        float *gbuf = ar.floats((size_t)Mo * Cout);
+        if (!gbuf) return fail("UpsamplerBlock backward: workspace too small");
+        if (mode) {
+            if (bn_backward(bn, pre, gy, premasked ? nullptr : y, nullptr, gbuf, dgamma, dbeta, Mo, Cout,
+                            4 * H * W, ar, st)) return 1;
+        } else {
+            if (launch_mask(gy, y, gbuf, Mo, Cout, st)) return 1;
+        }
+        g = gbuf;
     }
     const ParityTaps pt = parity_taps();
     Side *sd = dx ? side_stream() : nullptr;
@@ -927,6 +947,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
         IgemmDesc d;
         zero_desc(d);
         d.in = g; d.w = w; d.out = dx;
+        if (flags & ERF_BWD_MASK_DX) { d.epi.mask = x; d.epi.mask_C = Cin; }
         d.N = N; d.GH = H; d.GW = W;
         d.in_H = 2 * H; d.in_W = 2 * W; d.in_C = Cout; d.K = Cout; d.ss = 2;
         d.out_H = H; d.out_W = W; d.out_C = Cin; d.Nout = Cin;
@@ -955,7 +976,8 @@ int erf_outconv_forward(const float *x, const float *w, const float *b, float *y
 }
 
 int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw, float *db,
-                         int N, int Cin, int H, int W, int ncls, void *ws, size_t ws_bytes, void *stream)
+                         int N, int Cin, int H, int W, int ncls, int flags, void *ws, size_t ws_bytes,
+                         void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
@@ -970,7 +992,7 @@ int erf_outconv_backward(const float *x, const float *w, const float *gy, float 
     nsplit = (M + sp - 1) / sp;
     float *partial = ar.floats((size_t)nsplit * slab);
     if (!partial) return fail("output ConvTranspose2d backward: workspace too small");
-    OutConvBwdDesc d = {x, w, gy, dx, partial, N, H, W, ncls, (int)sp};
+    OutConvBwdDesc d = {x, w, gy, dx, partial, N, H, W, ncls, (int)sp, (flags & ERF_BWD_MASK_DX) ? 1 : 0};
     if (dx) {
         outconv_dgrad_kernel<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
         CHECK_LAUNCH("outconv_dgrad_kernel");

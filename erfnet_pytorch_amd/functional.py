@@ -95,6 +95,49 @@ def _arr(ts):
     return (vp * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
 
 
+# ReLU-mask hand-over between neighbouring blocks.  Every block output is a ReLU output, and the
+# first thing a block's backward does is mask the incoming gradient with (output > 0).  When the
+# input of block k is the output of block k-1, block k applies that mask to the dx it returns
+# (fused into its data-gradient epilogue) and leaves the tensor in the token both blocks share;
+# block k-1 skips its masking pass when the gradient autograd hands it IS that tensor, i.e. when
+# no other consumer contributed to it.  Masking is idempotent, so every other case (no token,
+# several consumers, a copy in between) simply takes the ordinary path.
+class _ReluToken:
+    __slots__ = ("dx",)
+
+    def __init__(self):
+        self.dx = None
+
+
+def _input_token(x):
+    return getattr(x, "_erf_relu_token", None)
+
+
+def _tag_output(y, token):
+    y._erf_relu_token = token
+    return y
+
+
+def _bwd_flags(ctx, gy):
+    """Flags for a backward call: is gy the pre-masked dx of the single consumer; may dx be masked."""
+    flags = 0
+    tok = ctx.out_token
+    if tok is not None and tok.dx is not None:
+        d = tok.dx
+        if d.data_ptr() == gy.data_ptr() and d.shape == gy.shape and d.stride() == gy.stride():
+            flags |= _lib.BWD_GY_PREMASKED
+        tok.dx = None
+    if ctx.in_token is not None:
+        flags |= _lib.BWD_MASK_DX
+    return flags
+
+
+def _hand_over(ctx, dx):
+    if ctx.in_token is not None and dx is not None:
+        ctx.in_token.dx = dx
+    return dx
+
+
 # Direct gradient write.  An owner of the parameters (ddp.GradientReducer) may attach
 # ``_erf_grad_sink = (buffer, owner)`` to a Parameter: backward then lets the weight-gradient kernel
 # write straight into ``buffer`` (the parameter's slice of a flat bucket) and returns None to
@@ -132,10 +175,12 @@ def _deliver(targets):
 # ------------------------------------------------------------------------------ DownsamplerBlock
 class _Downsampler(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, rm, rv, mode, momentum, eps):
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, mode, momentum, eps, out_token):
         lib = _lib.lib()
         n, cin, h, wd = x.shape
         cout = w.shape[0] + cin
+        ctx.in_token = _input_token(x) if cin != 3 else None
+        ctx.out_token = out_token
         if cin != 3 or ctx.needs_input_grad[0]:
             x = _nhwc(x)     # a 3-channel image is read through its strides unless dx is wanted
         elif x.dtype != torch.float32:
@@ -176,28 +221,33 @@ class _Downsampler(torch.autograd.Function):
         dw, db, dg, dbt = (t[0] for t in tg)
         ws = _workspace(x, n * (h // 2) * (wd // 2), cout)
         sn, sc, sh, sw = x.stride()
+        flags = _bwd_flags(ctx, gy) if need_dx else (_bwd_flags(ctx, gy) & _lib.BWD_GY_PREMASKED)
         with _dev_ctx(x):
             _lib.check(lib.erf_downsampler_backward(_p(x), sn, sc, sh, sw, _p(wq), bn.ref(), _p(y),
                                                     _p(pre), _p(gy), _p(dx), _p(dw), _p(db), _p(dg),
-                                                    _p(dbt), n, cin, h, wd, cout, _p(ws), ws.numel(),
-                                                    _stream(x)))
+                                                    _p(dbt), n, cin, h, wd, cout, flags, _p(ws),
+                                                    ws.numel(), _stream(x)))
         dw, db, dg, dbt = _deliver(tg)
-        return dx, dw, db, dg, dbt, None, None, None, None, None
+        return _hand_over(ctx, dx), dw, db, dg, dbt, None, None, None, None, None, None
 
 
 def downsampler(x, w, b, bn_weight=None, bn_bias=None, running_mean=None, running_var=None,
                 bn_mode=0, momentum=0.1, eps=1e-3):
     """DownsamplerBlock.forward of the reference (train/erfnet_blocks.py:25-29) on the GPU."""
-    return _Downsampler.apply(x, w, b, bn_weight if bn_mode else None, bn_bias if bn_mode else None,
-                              running_mean, running_var, bn_mode, momentum, eps)
+    tok = _ReluToken()
+    return _tag_output(_Downsampler.apply(x, w, b, bn_weight if bn_mode else None,
+                                          bn_bias if bn_mode else None, running_mean, running_var,
+                                          bn_mode, momentum, eps, tok), tok)
 
 
 # ------------------------------------------------------------------------------ non_bottleneck_1d
 class _Nb1d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w0, b0, w1, b1, w2, b2, w3, b3, g1, be1, g2, be2, rm1, rv1, rm2, rv2,
-                drop_scale, dil, mode, momentum, eps):
+                drop_scale, dil, mode, momentum, eps, out_token):
         lib = _lib.lib()
+        ctx.in_token = _input_token(x)
+        ctx.out_token = out_token
         x = _nhwc(x)
         n, c, h, wd = x.shape
         need = any(ctx.needs_input_grad)
@@ -242,12 +292,14 @@ class _Nb1d(torch.autograd.Function):
         dbs = [tg[i][0] for i in (1, 3, 5, 7)]
         dgs, dbts = [tg[8][0], tg[10][0]], [tg[9][0], tg[11][0]]
         ws = _workspace(x, n * h * wd, c)
+        flags = _bwd_flags(ctx, gy)
         with _dev_ctx(x):
             _lib.check(lib.erf_nb1d_backward(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
                                              dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
                                              _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
-                                             _p(ws), ws.numel(), _stream(x)))
-        return (dx, *_deliver(tg), None, None, None, None, None, None, None, None, None)
+                                             flags, _p(ws), ws.numel(), _stream(x)))
+        return (_hand_over(ctx, dx), *_deliver(tg), None, None, None, None, None, None, None, None, None,
+                None)
 
 
 def nb1d(x, weights, biases, dilated, bn1=None, bn2=None, bn_mode=0, drop_scale=None, momentum=0.1,
@@ -262,16 +314,19 @@ def nb1d(x, weights, biases, dilated, bn1=None, bn2=None, bn_mode=0, drop_scale=
     if bn_mode:
         g1, be1, rm1, rv1 = bn1
         g2, be2, rm2, rv2 = bn2
-    return _Nb1d.apply(x, weights[0], biases[0], weights[1], biases[1], weights[2], biases[2],
-                       weights[3], biases[3], g1, be1, g2, be2, rm1, rv1, rm2, rv2, drop_scale,
-                       dilated, bn_mode, momentum, eps)
+    tok = _ReluToken()
+    return _tag_output(_Nb1d.apply(x, weights[0], biases[0], weights[1], biases[1], weights[2], biases[2],
+                                   weights[3], biases[3], g1, be1, g2, be2, rm1, rv1, rm2, rv2,
+                                   drop_scale, dilated, bn_mode, momentum, eps, tok), tok)
 
 
 # ------------------------------------------------------------------------------ UpsamplerBlock
 class _Upsampler(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, rm, rv, mode, momentum, eps):
+    def forward(ctx, x, w, b, gamma, beta, rm, rv, mode, momentum, eps, out_token):
         lib = _lib.lib()
+        ctx.in_token = _input_token(x)
+        ctx.out_token = out_token
         x = _nhwc(x)
         n, cin, h, wd = x.shape
         cout = w.shape[1]
@@ -304,19 +359,24 @@ class _Upsampler(torch.autograd.Function):
         tg = _grad_targets(ctx.params, (wq.shape, (cout,), cvec, cvec), x.device)
         dw, db, dg, dbt = (t[0] for t in tg)
         ws = _workspace(x, n * 4 * h * wd, max(cin, cout))
+        flags = _bwd_flags(ctx, gy)
+        if dx is None:
+            flags &= _lib.BWD_GY_PREMASKED
         with _dev_ctx(x):
             _lib.check(lib.erf_upsampler_backward(_p(x), _p(wq), bn.ref(), _p(y), _p(pre), _p(gy), _p(dx),
                                                   _p(dw), _p(db), _p(dg), _p(dbt), n, cin, h, wd, cout,
-                                                  _p(ws), ws.numel(), _stream(x)))
+                                                  flags, _p(ws), ws.numel(), _stream(x)))
         dw, db, dg, dbt = _deliver(tg)
-        return dx, dw, db, dg, dbt, None, None, None, None, None
+        return _hand_over(ctx, dx), dw, db, dg, dbt, None, None, None, None, None, None
 
 
 def upsampler(x, w, b, bn_weight=None, bn_bias=None, running_mean=None, running_var=None, bn_mode=0,
               momentum=0.1, eps=1e-3):
     """UpsamplerBlock.forward of the reference (train/erfnet_blocks.py:84-88) on the GPU."""
-    return _Upsampler.apply(x, w, b, bn_weight if bn_mode else None, bn_bias if bn_mode else None,
-                            running_mean, running_var, bn_mode, momentum, eps)
+    tok = _ReluToken()
+    return _tag_output(_Upsampler.apply(x, w, b, bn_weight if bn_mode else None,
+                                        bn_bias if bn_mode else None, running_mean, running_var, bn_mode,
+                                        momentum, eps, tok), tok)
 
 
 # ------------------------------------------------------------------------------ output ConvTranspose2d
@@ -324,6 +384,7 @@ class _OutConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         lib = _lib.lib()
+        ctx.in_token = _input_token(x)
         x = _nhwc(x)
         n, cin, h, wd = x.shape
         ncls = w.shape[1]
@@ -351,11 +412,12 @@ class _OutConv(torch.autograd.Function):
         tg = _grad_targets(ctx.params, (wq.shape, (ncls,)), x.device)
         dw, db = tg[0][0], tg[1][0]
         ws = _workspace(x, n * h * wd, 16)
+        flags = _lib.BWD_MASK_DX if (ctx.in_token is not None and dx is not None) else 0
         with _dev_ctx(x):
             _lib.check(lib.erf_outconv_backward(_p(x), _p(wq), _p(gy), _p(dx), _p(dw), _p(db), n, cin, h,
-                                                wd, ncls, _p(ws), ws.numel(), _stream(x)))
+                                                wd, ncls, flags, _p(ws), ws.numel(), _stream(x)))
         dw, db = _deliver(tg)
-        return dx, dw, (db if ctx.has_bias else None)
+        return _hand_over(ctx, dx), dw, (db if ctx.has_bias else None)
 
 
 def outconv(x, w, b):

@@ -50,6 +50,15 @@ const char *erf_last_error(void);
  * prove the HIP path, not a fallback, produced a result). */
 unsigned long long erf_launch_count(void);
 
+/* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block
+ * receives is first masked by (its output > 0).  A block whose input x is itself such a ReLU
+ * output may apply the producer's mask to the dx it hands back (ERF_BWD_MASK_DX: dx *= (x > 0),
+ * fused into the data-gradient epilogue); the producer, told that the gradient it receives comes
+ * from exactly that consumer (ERF_BWD_GY_PREMASKED), skips its own masking pass.  Results for all
+ * parameter gradients and for dx of the first block are identical with and without the flags. */
+#define ERF_BWD_GY_PREMASKED 1
+#define ERF_BWD_MASK_DX 2
+
 /* Upper bound of the scratch bytes any entry point needs for an activation tensor of
  * n_pixels = N*H*W output pixels and at most max_c channels. */
 size_t erf_workspace_bytes(long long n_pixels, int max_c);
@@ -71,7 +80,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
                              long long sw, const float *w, const erf_bn_t *bn, const float *y,
                              const float *pre, const float *gy, float *dx, float *dw, float *db,
                              float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout,
-                             void *ws, size_t ws_bytes, void *stream);
+                             int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- non_bottleneck_1d (train/erfnet_blocks.py:33-73; eval/erfnet.py:26-61) -----------------
  * t1 = relu(conv3x1_1(x)); t2 = relu([bn1](conv1x3_1(t1))); t3 = relu(conv3x1_2(t2));
@@ -91,7 +100,7 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
                       const erf_bn_t *bn2, const float *drop_scale, int dil, const float *y,
                       const float *const save[5], const float *gy, float *dx, float *const dw[4],
                       float *const db[4], float *const dgamma[2], float *const dbeta[2], int N,
-                      int C, int H, int W, void *ws, size_t ws_bytes, void *stream);
+                      int C, int H, int W, int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- UpsamplerBlock (train/erfnet_blocks.py:77-88; eval/erfnet.py:99-108) -------------------
  * y = relu([bn](ConvTranspose2d(Cin,Cout,3,stride 2,padding 1,output_padding 1)(x)))
@@ -102,7 +111,7 @@ int erf_upsampler_forward(const float *x, const float *w, const float *b, const 
 int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, const float *y,
                            const float *pre, const float *gy, float *dx, float *dw, float *db,
                            float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout,
-                           void *ws, size_t ws_bytes, void *stream);
+                           int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- output ConvTranspose2d(Cin, ncls, 2, stride=2) (train/net_classification.py:56,64;
  *      eval/erfnet.py:124,132; train/erfnet_blocks.py:99) --------------------------------------
@@ -114,7 +123,7 @@ int erf_outconv_forward(const float *x, const float *w, const float *b, float *y
                         int H, int W, int ncls, int softmax, void *stream);
 /* gy NCHW [N,ncls,2H,2W] = gradient w.r.t. the conv output (pre-softmax); dx NHWC. */
 int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw,
-                         float *db, int N, int Cin, int H, int W, int ncls, void *ws,
+                         float *db, int N, int Cin, int H, int W, int ncls, int flags, void *ws,
                          size_t ws_bytes, void *stream);
 
 /* ---- plain nn.Conv2d on NHWC tensors (Encoder.output_conv 1x1, eval/erfnet.py:85,93-94;

@@ -177,9 +177,23 @@ def test_nb1d_c_abi_against_oracle(C_, dil, N, H, W):
     none2 = (C.c_void_p * 2)(None, None)
     _lib.check(lib.erf_nb1d_backward(_dptr(dx_), arr(dws), None, None, None, dil, _dptr(y_ref_d),
                                      parr, _dptr(gy_d), _dptr(dx), arr(gdw), arr(gdb), none2,
-                                     none2, N, C_, H, W, _dptr(wsb), wsb.numel(), None))
+                                     none2, N, C_, H, W, 0, _dptr(wsb), wsb.numel(), None))
     torch.cuda.synchronize()
     gu.check_arrays(_to_nchw(dx, x.shape), dx_ref, 5e-4, 5e-4, what="dx", scale_rtol=1e-4)
+    # the same call with the incoming gradient already masked by (y > 0) and dx masked by (x > 0):
+    # parameter gradients bit-identical, dx identical wherever x > 0 and zero elsewhere
+    gy_m = (gy_d * (y_ref_d > 0)).contiguous()
+    dx2 = torch.empty(nel, device=DEV)
+    gdw2 = [torch.empty(w.size, device=DEV) for w in ws]
+    gdb2 = [torch.empty(C_, device=DEV) for _ in range(4)]
+    _lib.check(lib.erf_nb1d_backward(_dptr(dx_), arr(dws), None, None, None, dil, _dptr(y_ref_d),
+                                     parr, _dptr(gy_m), _dptr(dx2), arr(gdw2), arr(gdb2), none2,
+                                     none2, N, C_, H, W, _lib.BWD_GY_PREMASKED | _lib.BWD_MASK_DX,
+                                     _dptr(wsb), wsb.numel(), None))
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert torch.equal(gdw[i], gdw2[i]) and torch.equal(gdb[i], gdb2[i])
+    assert torch.equal(dx2, dx * (dx_.reshape(-1) > 0))
     for i in range(4):
         gu.check_arrays(gdw[i].cpu().numpy().reshape(ws[i].shape), dws_ref[i], 5e-4, 5e-4,
                         what=f"dw{i}", scale_rtol=2e-4)
@@ -384,6 +398,35 @@ def test_cross_entropy_nothing_labelled_is_nan():
     lab = torch.full((1, 8, 8), -1, dtype=torch.int64, device=DEV)
     assert torch.isnan(CrossEntropyLoss2d()(x, lab))
     assert torch.isnan(torch.nn.functional.cross_entropy(x, lab, ignore_index=-1))
+
+
+def test_relu_mask_hand_over_leaves_gradients_unchanged(monkeypatch):
+    """Neighbouring blocks hand the ReLU mask of the gradient over (consumer masks its dx, producer
+    skips its masking pass).  Every parameter gradient and the input gradient must be bit-identical
+    to the run in which no block knows its neighbour."""
+    from erfnet_pytorch_amd import functional as hipf
+    x_np = gu.det_uniform("handover.x", (2, 3, 64, 128), 0.0, 1.0)
+    lab = t(gu.det_labels("handover.lab", (2, 64, 128), -1, 20))
+    res = []
+    for hand_over in (True, False):
+        if not hand_over:
+            monkeypatch.setattr(hipf, "_input_token", lambda x: None)
+        net = gu.fill_state_dict(make_model("net_classification_20"), tag="trainstep").to(DEV).train()
+        for m in net.modules():           # dropout off: both runs must see the same network
+            if isinstance(m, torch.nn.Dropout2d):
+                m.p = 0.0
+        x = t(x_np).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        n0 = launches()
+        out, _ = net(x)
+        torch.nn.functional.cross_entropy(out, lab, ignore_index=-1).backward()
+        res.append(({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
+                    x.grad.clone(), launches() - n0))
+    (ga, xa, la), (gb, xb, lb) = res
+    assert la < lb                        # the masking passes really were skipped
+    assert ga.keys() == gb.keys()
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    assert torch.equal(xa, xb)
 
 
 # ------------------------------------------------------------- full benchmark size: properties
