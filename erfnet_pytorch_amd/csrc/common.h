@@ -107,6 +107,11 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned by
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
 }
 
+#define ERF_WGRAD_BATCH 4
+struct WgradBatch {
+    WgradDesc d[ERF_WGRAD_BATCH];
+};
+
 __device__ __forceinline__ float apply_bn(const BnAffine &bn, float v, int c)
 {
     const float inv = bn.var_is_invstd ? bn.var[c] : rsqrtf(bn.var[c] + bn.eps);

@@ -33,58 +33,6 @@ int fail(const char *fmt, ...)
         g_launches.fetch_add(1, std::memory_order_relaxed);                                        \
     } while (0)
 
-// Helper stream for work that is off the critical path of a backward call (weight gradients run
-// beside the data-gradient chain and fill the launch / write-back gaps of its kernels).  One low
-// priority stream and a few events per host thread and device, created on first use; every call
-// that forks work onto it joins it back into the caller's stream before returning, so from the
-// caller's side all work is ordered on the stream it passed.  Off by default (measured neutral on
-// the whole training step: the data-gradient kernels leave too little LDS for a second resident
-// kernel); ERFNET_SIDE_STREAM=1 turns it on.
-struct Side {
-    hipStream_t s = nullptr;
-    hipEvent_t fork[4] = {nullptr, nullptr, nullptr, nullptr}, join = nullptr;
-    int state = 0;      // 0 = not created, 1 = ready, -1 = unavailable
-};
-thread_local Side g_side[32];
-
-Side *side_stream()
-{
-    static int enabled = -1;
-    if (enabled < 0) { const char *e = getenv("ERFNET_SIDE_STREAM"); enabled = (e && atoi(e)) ? 1 : 0; }
-    if (!enabled) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return nullptr;
-    Side &sd = g_side[dev];
-    if (sd.state == 0) {
-        sd.state = -1;
-        int lo = 0, hi = 0;
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; }
-        if (hipStreamCreateWithPriority(&sd.s, hipStreamNonBlocking, lo) != hipSuccess) return nullptr;
-        bool ok = hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreateWithFlags(&sd.fork[i], hipEventDisableTiming) == hipSuccess;
-        if (ok) sd.state = 1;
-    }
-    return sd.state == 1 ? &sd : nullptr;
-}
-// Work queued on the returned stream starts after everything queued on `main` so far.
-hipStream_t side_fork(Side *sd, int i, hipStream_t main)
-{
-    if (!sd) return main;
-    if (hipEventRecord(sd->fork[i], main) != hipSuccess || hipStreamWaitEvent(sd->s, sd->fork[i], 0) != hipSuccess) {
-        (void)hipGetLastError();
-        return main;
-    }
-    return sd->s;
-}
-// Everything queued on the side stream so far completes before later work on `main`.
-int side_join(Side *sd, hipStream_t main)
-{
-    if (!sd) return 0;
-    if (hipEventRecord(sd->join, sd->s) != hipSuccess || hipStreamWaitEvent(main, sd->join, 0) != hipSuccess)
-        return fail("side stream join failed: %s", hipGetErrorString(hipGetLastError()));
-    return 0;
-}
-
 // Bump allocator over the caller's workspace (256-byte granules).
 struct Arena {
     char *base;
@@ -286,36 +234,51 @@ int launch_igemm(IgemmDesc &d, Arena &ar, hipStream_t st)
     return run_igemm(d, st);
 }
 
-// Sum the slabs of a weight-gradient launch into torch's layout.
-int launch_reduce(const WgradDesc &d, float *dw, float *db, const int *woff, int wsk, int wsn,
-                  unsigned bias_taps, hipStream_t st)
+// Weight gradients of up to four convolutions of identical geometry (the four 1-D convolutions of
+// a non_bottleneck_1d) in one launch (blockIdx.z = convolution) followed by one slab reduction
+// (blockIdx.y = convolution): one launch ramp and one tail instead of four.  `in`/`g`/taps may
+// differ per convolution; K, Nout, ntaps, the pixel grid and the strides must agree.
+// `bias_taps`: bit t set = the bias row of tap t enters db (taps whose g pixels partition the
+// gradient tensor).
+int launch_reduce_batch(const WgradDesc *d, int n, float *const *dw, float *const *db, const int *woff,
+                        int wsk, int wsn, unsigned bias_taps, hipStream_t st)
 {
-    ReduceDesc r;
-    r.partial = d.partial; r.dw = dw; r.db = db;
-    r.nsplit = d.nsplit; r.ntaps = d.ntaps; r.K = d.K; r.Nout = d.Nout;
-    for (int t = 0; t < d.ntaps; ++t) r.woff[t] = woff[t];
-    r.wsk = wsk; r.wsn = wsn; r.bias_taps = bias_taps;
-    const long long tot = (long long)d.ntaps * d.K * d.Nout + d.Nout;
-    reduce_partials_kernel<<<(unsigned)((tot + 31) / 32), 256, 0, st>>>(r);
+    ReduceBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    for (int i = 0; i < n; ++i) {
+        ReduceDesc &r = rb.r[i];
+        r.partial = d[i].partial; r.dw = dw[i]; r.db = db ? db[i] : nullptr;
+        r.nsplit = d[i].nsplit; r.ntaps = d[i].ntaps; r.K = d[i].K; r.Nout = d[i].Nout;
+        for (int t = 0; t < d[i].ntaps; ++t) r.woff[t] = woff[t];
+        r.wsk = wsk; r.wsn = wsn; r.bias_taps = bias_taps;
+    }
+    const long long tot = (long long)d[0].ntaps * d[0].K * d[0].Nout + d[0].Nout;
+    reduce_partials_kernel<<<dim3((unsigned)((tot + 31) / 32), n, 1), 256, 0, st>>>(rb);
     CHECK_LAUNCH("reduce_partials_kernel");
     return 0;
 }
 
-// Weight gradient + slab reduction into torch's layout.  `bias_taps`: bit t set = the bias row of
-// tap t enters db (taps whose g pixels partition the gradient tensor).
-int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, int wsn,
-                 unsigned bias_taps, Arena &ar, hipStream_t st)
+int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db, const int *woff, int wsk,
+                       int wsn, unsigned bias_taps, Arena &ar, hipStream_t st)
 {
+    if (n < 1 || n > ERF_WGRAD_BATCH) return fail("wgrad: batch of %d", n);
+    WgradDesc &d = dd[0];
     const long long M = (long long)d.N * d.GH * d.GW;
     if (M >= (1LL << 31)) return fail("wgrad: more than 2^31 pixels");
-    if ((long long)d.N * d.in_H * d.in_W * d.in_C >= (1LL << 29) || (long long)d.N * d.g_H * d.g_W * d.g_C >= (1LL << 29))
-        return fail("wgrad: tensors of 2 GiB or more are not supported");
-    d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && d.g_C % 4 == 0 &&
-                d.g_coff % 4 == 0 && d.Nout % 4 == 0 && aligned16(d.in) && aligned16(d.g)) ? 1 : 0;
-    if (stream16_enabled() && d.K == 16 && d.Nout == 16 && d.ntaps == 3 && d.ss == 1 && d.os == 1 &&
-        d.in_H == d.GH && d.in_W == d.GW && d.g_H == d.GH && d.g_W == d.GW && d.GW >= 16 &&
-        M * d.in_C < (1LL << 29) && M * d.g_C < (1LL << 29) && !d.toa[0] && !d.tob[0] && !d.toa[1] &&
-        !d.tob[1] && !d.toa[2] && !d.tob[2]) {
+    bool vec = true, s16 = stream16_enabled() && d.K == 16 && d.Nout == 16 && d.ntaps == 3 && d.ss == 1 &&
+                          d.os == 1 && d.in_H == d.GH && d.in_W == d.GW && d.g_H == d.GH && d.g_W == d.GW &&
+                          d.GW >= 16;
+    for (int i = 0; i < n; ++i) {
+        const WgradDesc &e = dd[i];
+        if (e.K != d.K || e.Nout != d.Nout || e.ntaps != d.ntaps || e.N != d.N || e.GH != d.GH || e.GW != d.GW)
+            return fail("wgrad: batched convolutions differ in geometry");
+        if ((long long)e.N * e.in_H * e.in_W * e.in_C >= (1LL << 29) || (long long)e.N * e.g_H * e.g_W * e.g_C >= (1LL << 29))
+            return fail("wgrad: tensors of 2 GiB or more are not supported");
+        vec = vec && e.in_C % 4 == 0 && e.in_coff % 4 == 0 && e.K % 4 == 0 && e.g_C % 4 == 0 &&
+              e.g_coff % 4 == 0 && e.Nout % 4 == 0 && aligned16(e.in) && aligned16(e.g);
+        s16 = s16 && !e.toa[0] && !e.tob[0] && !e.toa[1] && !e.tob[1] && !e.toa[2] && !e.tob[2];
+    }
+    if (s16) {      // 16 -> 16 channels: streaming kernel, one launch per convolution
         constexpr int NW = 8;
         const size_t slab = 3 * 256 + 3 * 16;
         long long nsplit = (M + NW * 64 - 1) / (NW * 64);          // >= 4 MFMA groups per wave
@@ -324,16 +287,19 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
         long long sp = (M + nsplit - 1) / nsplit;
         sp = (sp + NW * 16 - 1) / (NW * 16) * (NW * 16);
         nsplit = (M + sp - 1) / sp;
-        d.nsplit = (int)nsplit;
-        d.split_pixels = (int)sp;
-        d.partial = ar.floats(slab * nsplit);
-        if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
-        wgrad16_kernel<3, NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(d);
-        CHECK_LAUNCH("wgrad16_kernel");
-        return launch_reduce(d, dw, db, woff, wsk, wsn, bias_taps, st);
+        for (int i = 0; i < n; ++i) {
+            WgradDesc &e = dd[i];
+            e.nsplit = (int)nsplit;
+            e.split_pixels = (int)sp;
+            e.partial = ar.floats(slab * nsplit);
+            if (!e.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
+            wgrad16_kernel<3, NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e);
+            CHECK_LAUNCH("wgrad16_kernel");
+        }
+        return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);
     }
     int IBLK, JBLK, cfg;
-    if (!d.vec_ok) { IBLK = 32; JBLK = 32; cfg = 7; }
+    if (!vec) { IBLK = 32; JBLK = 32; cfg = 7; }
     else if (d.K > 64 && d.Nout > 64) { IBLK = 128; JBLK = 128; cfg = 0; }
     else if (d.K > 64 && d.Nout > 32) { IBLK = 128; JBLK = 64; cfg = 1; }
     else if (d.K > 32 && d.Nout > 64) { IBLK = 64; JBLK = 128; cfg = 2; }
@@ -341,9 +307,8 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     else if (d.K <= 32 && d.Nout > 32) { IBLK = 32; JBLK = 64; cfg = 4; }
     else if (d.K > 32) { IBLK = 64; JBLK = 32; cfg = 5; }
     else { IBLK = 32; JBLK = 32; cfg = 6; }
-    d.itiles = (d.K + IBLK - 1) / IBLK;
-    d.jtiles = (d.Nout + JBLK - 1) / JBLK;
-    const int tiles = d.ntaps * d.itiles * d.jtiles;
+    const int itiles = (d.K + IBLK - 1) / IBLK, jtiles = (d.Nout + JBLK - 1) / JBLK;
+    const int tiles = d.ntaps * itiles * jtiles;
     const size_t slab = (size_t)d.ntaps * d.K * d.Nout + (size_t)d.ntaps * d.Nout;
     // Pixels are split in slabs of `spb` 32-pixel steps.  Blocks are dealt round-robin over the
     // 256 CUs and co-resident blocks share the MFMA pipe, so the kernel lasts as long as the CU
@@ -357,31 +322,47 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     double best = 1e30;
     for (long long spb = 2; spb <= steps; ++spb) {
         const long long ns = (steps + spb - 1) / spb;
-        if (ns * (long long)(slab * sizeof(float)) > (64LL << 20)) continue;
-        const long long per_cu = (tiles * ns + 255) / 256;
-        double t = per_cu * spb * t_step * (per_cu == 1 ? 1.25 : 1.0) + ns * slab_us;
+        if (ns * (long long)(slab * sizeof(float)) * n > (96LL << 20)) continue;
+        const long long per_cu = ((long long)n * tiles * ns + 255) / 256;
+        double t = per_cu * spb * t_step * (per_cu == 1 ? 1.25 : 1.0) + n * ns * slab_us;
         if (t < best) { best = t; best_spb = spb; }
     }
     if (forced_spb > 0) best_spb = forced_spb < steps ? forced_spb : steps;
     const long long sp = best_spb * 32;
     const long long nsplit = (M + sp - 1) / sp;
-    d.nsplit = (int)nsplit;
-    d.split_pixels = (int)sp;
-    d.partial = ar.floats(slab * nsplit);
-    if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
-    dim3 grid((unsigned)nsplit, tiles, 1);
+    WgradBatch wb;
+    memset(&wb, 0, sizeof(wb));
+    for (int i = 0; i < n; ++i) {
+        WgradDesc &e = dd[i];
+        e.vec_ok = vec ? 1 : 0;
+        e.itiles = itiles; e.jtiles = jtiles;
+        e.nsplit = (int)nsplit;
+        e.split_pixels = (int)sp;
+        e.partial = ar.floats(slab * nsplit);
+        if (!e.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit * n);
+        wb.d[i] = e;
+    }
+    dim3 grid((unsigned)nsplit, tiles, n);
     switch (cfg) {
-    case 0: wgrad_f32_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
-    case 1: wgrad_f32_kernel<2, 1, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
-    case 2: wgrad_f32_kernel<1, 2, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
-    case 3: wgrad_f32_kernel<1, 1, 2, 2, true><<<grid, 256, 0, st>>>(d); break;
-    case 4: wgrad_f32_kernel<1, 1, 1, 2, true><<<grid, 128, 0, st>>>(d); break;
-    case 5: wgrad_f32_kernel<1, 1, 2, 1, true><<<grid, 128, 0, st>>>(d); break;
-    case 6: wgrad_f32_kernel<1, 1, 1, 1, true><<<grid, 64, 0, st>>>(d); break;
-    default: wgrad_f32_kernel<1, 1, 1, 1, false><<<grid, 64, 0, st>>>(d); break;
+    case 0: wgrad_f32_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
+    case 1: wgrad_f32_kernel<2, 1, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
+    case 2: wgrad_f32_kernel<1, 2, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
+    case 3: wgrad_f32_kernel<1, 1, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
+    case 4: wgrad_f32_kernel<1, 1, 1, 2, true><<<grid, 128, 0, st>>>(wb); break;
+    case 5: wgrad_f32_kernel<1, 1, 2, 1, true><<<grid, 128, 0, st>>>(wb); break;
+    case 6: wgrad_f32_kernel<1, 1, 1, 1, true><<<grid, 64, 0, st>>>(wb); break;
+    default: wgrad_f32_kernel<1, 1, 1, 1, false><<<grid, 64, 0, st>>>(wb); break;
     }
     CHECK_LAUNCH("wgrad_f32_kernel");
-    return launch_reduce(d, dw, db, woff, wsk, wsn, bias_taps, st);
+    return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);
+}
+
+// Single convolution.
+int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, int wsn,
+                 unsigned bias_taps, Arena &ar, hipStream_t st)
+{
+    float *dws[1] = {dw}, *dbs[1] = {db};
+    return launch_wgrad_batch(&d, 1, dws, dbs, woff, wsk, wsn, bias_taps, ar, st);
 }
 
 unsigned grid_for(long long work_items, int per_block = 256, unsigned cap = 8192)
@@ -547,7 +528,7 @@ unsigned long long erf_launch_count(void) { return g_launches.load(); }
 size_t erf_workspace_bytes(long long n_pixels, int max_c)
 {
     // six gradient/activation temporaries + weight-gradient slabs + BatchNorm sums + slack
-    return (size_t)n_pixels * (size_t)max_c * sizeof(float) * 6 + (size_t)(96u << 20);
+    return (size_t)n_pixels * (size_t)max_c * sizeof(float) * 6 + (size_t)(136u << 20);
 }
 
 // ================================================================================ Downsampler
@@ -634,7 +615,6 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         }
         g = gbuf;
     }
-    Side *sd = nullptr;
     if (Cin == 3) {
         const int nw = Cc * 27;
         long long nsplit = (Mo + 2047) / 2048;
@@ -658,8 +638,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         int woff[9];
         for (int t = 0; t < 9; ++t) { d.tdh[t] = t / 3 - 1; d.tdw[t] = t % 3 - 1; woff[t] = t; }
         d.g_H = Ho; d.g_W = Wo; d.g_C = Cout; d.Nout = Cc;
-        sd = dx ? side_stream() : nullptr;        // beside the data gradient, when there is one
-        if (launch_wgrad(d, dw, db, woff, 9, Cin * 9, 1u, ar, side_fork(sd, 0, st))) return 1;
+        if (launch_wgrad(d, dw, db, woff, 9, Cin * 9, 1u, ar, st)) return 1;
     }
     if (dx) {
         // dx is NHWC [N,H,W,Cin]: max-pool gradient first, then the conv data gradient on top.
@@ -686,7 +665,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         d.wsk = Cin * 9; d.wsn = 9;   // W[co][ci][kh][kw]: k = co, j = ci
         if (launch_igemm(d, ar, st)) return 1;
     }
-    return side_join(sd, st);
+    return 0;
 }
 
 // ================================================================================ non_bottleneck_1d
@@ -795,7 +774,6 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     if ((!premasked && !g4buf) || !ga || !gb || !g1 || ((m2 || drop_scale) && !gsbuf) || (m1 && !gnbuf))
         return fail("non_bottleneck_1d backward: workspace too small");
     const int woff[3] = {0, 1, 2};
-    WgradDesc wd;
 
     IgemmDesc d[4];
     PackDesc pk[4];
@@ -811,15 +789,11 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     for (int i = 0; i < 4; ++i)
         if (plan_igemm(d[i], ar, pk[i])) return 1;
     if (launch_pack(pk, 4, st)) return 1;
-    // BatchNorm scratch (caller's stream) first, then the slab region the four weight gradients
-    // share: they run one after the other on one stream.
+    // BatchNorm scratch first; the slabs of the four weight gradients follow it
     const size_t bn_bytes = 2 * (sizeof(double) * 2 * (size_t)C + 256);
     void *pbn = ar.take(bn_bytes);
     if (!pbn) return fail("non_bottleneck_1d backward: workspace too small");
     Arena bn_ar(pbn, bn_bytes);
-    const size_t ws_mark = ar.off;
-    Side *sd = side_stream();
-
     // g4 = gy * (y > 0): gradient of the residual sum (goes to x unchanged and into the conv branch)
     if (!premasked && launch_mask(gy, y, g4buf, M, C, st)) return 1;
     if (m2) {
@@ -830,35 +804,22 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
         e.nscale = drop_scale;
         if (launch_elt(g4, gsbuf, e, M, C, H * W, st)) return 1;
     }
-    // conv1x3_2: weight gradient from (t3, gs); data gradient -> gb
-    hipStream_t ss = side_fork(sd, 0, st);
-    ar.off = ws_mark;
-    wgrad1d_desc(wd, t3, gs, N, C, H, W, 1, dil);
-    if (launch_wgrad(wd, dw[3], db[3], woff, 3, C * 3, 1u, ar, ss)) return 1;
+    // data-gradient chain: gs -> gb -> ga [-> gn] -> g1 -> dx = dgrad + g4
     if (run_igemm(d[3], st)) return 1;
-    // conv3x1_2: (t2, gb) -> ga
-    ss = side_fork(sd, 1, st);
-    ar.off = ws_mark;
-    wgrad1d_desc(wd, t2, gb, N, C, H, W, 0, dil);
-    if (launch_wgrad(wd, dw[2], db[2], woff, 3, C * 3, 1u, ar, ss)) return 1;
     if (run_igemm(d[2], st)) return 1;
     if (m1) {
         if (bn_backward(bn1, p2, ga, nullptr, nullptr, gnbuf, dgamma ? dgamma[0] : nullptr,
                         dbeta ? dbeta[0] : nullptr, M, C, H * W, bn_ar, st)) return 1;
     }
-    // conv1x3_1: (t1, gn) -> g1
-    ss = side_fork(sd, 2, st);
-    ar.off = ws_mark;
-    wgrad1d_desc(wd, t1, gn, N, C, H, W, 1, 1);
-    if (launch_wgrad(wd, dw[1], db[1], woff, 3, C * 3, 1u, ar, ss)) return 1;
     if (run_igemm(d[1], st)) return 1;
-    // conv3x1_1: (x, g1) -> dx = dgrad + g4
-    ss = side_fork(sd, 3, st);
-    ar.off = ws_mark;
-    wgrad1d_desc(wd, x, g1, N, C, H, W, 0, 1);
-    if (launch_wgrad(wd, dw[0], db[0], woff, 3, C * 3, 1u, ar, ss)) return 1;
     if (run_igemm(d[0], st)) return 1;
-    return side_join(sd, st);
+    // the four weight gradients in one launch: (x, g1), (t1, gn), (t2, gb), (t3, gs)
+    WgradDesc wd[4];
+    wgrad1d_desc(wd[0], x, g1, N, C, H, W, 0, 1);
+    wgrad1d_desc(wd[1], t1, gn, N, C, H, W, 1, 1);
+    wgrad1d_desc(wd[2], t2, gb, N, C, H, W, 0, dil);
+    wgrad1d_desc(wd[3], t3, gs, N, C, H, W, 1, dil);
+    return launch_wgrad_batch(wd, 4, dw, db, woff, 3, C * 3, 1u, ar, st);
 }
 
 // ================================================================================ Upsampler
@@ -928,8 +889,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
         g = gbuf;
     }
     const ParityTaps pt = parity_taps();
-    Side *sd = dx ? side_stream() : nullptr;
-    {   // weight gradient over the parity classes (beside the data gradient)
+    {   // weight gradient over the parity classes
         WgradDesc d;
         memset(&d, 0, sizeof(d));
         d.in = x; d.g = g;
@@ -941,7 +901,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
             woff[t] = pt.kh[t] * 3 + pt.kw[t];
         }
         d.g_H = 2 * H; d.g_W = 2 * W; d.g_C = Cout; d.Nout = Cout;
-        if (launch_wgrad(d, dw, db, woff, Cout * 9, 9, pt.rep_mask, ar, side_fork(sd, 0, st))) return 1;
+        if (launch_wgrad(d, dw, db, woff, Cout * 9, 9, pt.rep_mask, ar, st)) return 1;
     }
     if (dx) {   // data gradient = ordinary 3x3 stride-2 convolution of g
         IgemmDesc d;
@@ -956,7 +916,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
         d.wsk = 9; d.wsn = Cout * 9;   // W[ci][co][kh][kw]: k = co, j = ci
         if (launch_igemm(d, ar, st)) return 1;
     }
-    return side_join(sd, st);
+    return 0;
 }
 
 // ================================================================================ output conv
@@ -1059,8 +1019,7 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
     int woff[9];
     conv2d_taps(k, wd.tdh, wd.tdw, woff, false);
     wd.g_H = H; wd.g_W = W; wd.g_C = Cout; wd.Nout = Cout;
-    Side *sd = dx ? side_stream() : nullptr;
-    if (launch_wgrad(wd, dw, db, woff, k * k, Cin * k * k, 1u, ar, side_fork(sd, 0, st))) return 1;
+    if (launch_wgrad(wd, dw, db, woff, k * k, Cin * k * k, 1u, ar, st)) return 1;
     if (dx) {
         IgemmDesc d;
         zero_desc(d);
@@ -1073,7 +1032,7 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
         d.wsk = Cin * k * k; d.wsn = k * k;
         if (launch_igemm(d, ar, st)) return 1;
     }
-    return side_join(sd, st);
+    return 0;
 }
 
 // ================================================================================ CrossEntropyLoss2d

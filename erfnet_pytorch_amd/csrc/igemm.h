@@ -292,8 +292,9 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 // LDS: X tile [32 pixels][IBLK], G tile [32 pixels][JBLK]; MFMA operands are read with ds_read_b32
 // (lanes walk the channel, the two lane halves take pixel 2s and 2s+1).
 template <int IB, int JB, int GI, int GJ, bool VEC>
-__global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradDesc d)
+__global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradBatch batch)
 {
+    const WgradDesc &d = batch.d[blockIdx.z];      // up to four convolutions per launch
     constexpr int IBLK = GI * IB * 32, JBLK = GJ * JB * 32, NT = GI * GJ * 64;
     constexpr int PM = 32;
     constexpr int XV = PM * IBLK / 4, GV = PM * JBLK / 4;        // float4 slots per tile
@@ -485,8 +486,13 @@ struct ReduceDesc {
 
 // Block = 32 consecutive slab elements x 8 slab groups: thread (g, e) sums slabs g, g+8, ... of
 // element e, the 8 group sums are then added in a fixed order through LDS.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceDesc d)
+struct ReduceBatch {
+    ReduceDesc r[ERF_WGRAD_BATCH];
+};
+
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceBatch batch)
 {
+    const ReduceDesc &d = batch.r[blockIdx.y];
     __shared__ float red[8][33];
     const long long nw = (long long)d.ntaps * d.K * d.Nout;
     const long long slab = nw + (long long)d.ntaps * d.Nout;
