@@ -107,6 +107,16 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned by
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
 }
 
+// Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.
+// Tiles that share input rows (the taps of a convolution reach d rows up and down) should meet in
+// one L2, so the tile index is remapped: XCD x works through the x-th contiguous eighth of the
+// tiles in order.  Only a locality hint — correctness does not depend on the hardware's mapping.
+__device__ __forceinline__ unsigned xcd_tile(unsigned bid, unsigned nb)
+{
+    const unsigned q = nb >> 3, r = nb & 7u, x = bid & 7u, slot = bid >> 3;
+    return x < r ? x * (q + 1) + slot : r * (q + 1) + (x - r) * q + slot;
+}
+
 #define ERF_WGRAD_BATCH 4
 struct WgradBatch {
     WgradDesc d[ERF_WGRAD_BATCH];

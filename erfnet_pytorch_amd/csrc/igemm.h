@@ -96,7 +96,7 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
     const int l31 = lane & 31, h = lane >> 5;
     const int grp = blockIdx.z;
     const long long M = (long long)d.N * d.GH * d.GW;
-    const long long m0 = (long long)blockIdx.x * BM;
+    const long long m0 = (long long)xcd_tile(blockIdx.x, gridDim.x) * BM;
     const int j0 = blockIdx.y * BN;
 
     for (int r = tid; r < BM; r += NT) {
