@@ -99,6 +99,41 @@ def dominant_kernel_roofline(device, batch):
             "hbm_bound_us": round(2 * pixels * DOM_C * 4 / 8e12 * 1e6, 2)}
 
 
+def forward_time_harness(device, batch=1, iters=20):
+    """The reference's forward-time script (eval/eval_forwardTime.py:22-58): erfnet_nobn.ERFNet(19)
+    in eval mode on a fixed torch.randn(B,3,512,1024), device synchronised around every call, the
+    first call excluded, seconds per image = t / B (the script's sleep(1) between calls dropped)."""
+    from erfnet_pytorch_amd import erfnet_nobn
+    model = erfnet_nobn.ERFNet(19).to(device).eval()
+    images = torch.randn(batch, 3, HEIGHT, WIDTH, generator=torch.Generator().manual_seed(0)).to(device)
+    times = []
+    with torch.no_grad():
+        for i in range(iters + 1):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            model(images)
+            torch.cuda.synchronize(device)
+            if i:
+                times.append(time.perf_counter() - t0)
+    out = {"model": "erfnet_nobn.ERFNet(19)", "batch": batch, "input": "randn 3x512x1024, fp32",
+           "ms_per_img_mean": round(sum(times) / len(times) / batch * 1e3, 4),
+           "ms_per_img_min": round(min(times) / batch * 1e3, 4)}
+    # the same loop with the forward captured once into a HIP graph (one launch per call)
+    from erfnet_pytorch_amd.graphs import GraphedForward
+    graphed = GraphedForward(model, images)
+    times = []
+    for i in range(iters + 1):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        graphed(images)
+        torch.cuda.synchronize(device)
+        if i:
+            times.append(time.perf_counter() - t0)
+    out["hip_graph_ms_per_img_mean"] = round(sum(times) / len(times) / batch * 1e3, 4)
+    out["hip_graph_ms_per_img_min"] = round(min(times) / batch * 1e3, 4)
+    return out
+
+
 def cpu_baseline():
     """The plain-C oracle (a port of the reference's arithmetic) timed on this host's cores:
     forward + CrossEntropy + backward of ONE 512x1024 image (no optimiser step)."""
@@ -216,6 +251,8 @@ def main():
             torch.cuda.synchronize(device)
             fwd_ms = (time.perf_counter() - t1) / 5 / args.batch * 1e3
 
+    h1 = forward_time_harness(device) if rank == 0 else None
+
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
         rec = {
@@ -239,6 +276,7 @@ def main():
                        "parallelism": f"dp{world}",
                        "grad_buckets_bytes": reducer.bucket_sizes},
             "fwd_ms_per_img": round(fwd_ms, 4),
+            "forward_time_harness": h1,
             "final_loss": round(final_loss, 5),
         }
         if world == 1:

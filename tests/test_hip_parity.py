@@ -429,6 +429,23 @@ def test_relu_mask_hand_over_leaves_gradients_unchanged(monkeypatch):
     assert torch.equal(xa, xb)
 
 
+def test_graphed_forward_replays_the_eager_result():
+    """A forward captured into a HIP graph (graphs.GraphedForward) returns bit-identical logits on
+    replay, for the captured input and for new data of the same shape."""
+    from erfnet_pytorch_amd.graphs import GraphedForward
+    net = gu.fill_state_dict(make_model("eval_erfnet_nobn_19"), tag="eval_erfnet_nobn_19").to(DEV).eval()
+    x1 = t(gu.det_uniform("graph.x1", (1, 3, 64, 128), 0.0, 1.0))
+    x2 = t(gu.det_uniform("graph.x2", (1, 3, 64, 128), 0.0, 1.0))
+    with torch.no_grad():
+        y1, y2 = first(net(x1)).clone(), first(net(x2)).clone()
+    g = GraphedForward(net, x1)
+    assert torch.equal(first(g(x1)), y1)
+    assert torch.equal(first(g(x2)), y2)
+    assert torch.equal(first(g(x1)), y1)
+    with pytest.raises(ValueError):
+        g(x1[:, :, :32])
+
+
 # ------------------------------------------------------------- full benchmark size: properties
 def _torch_nb1d(x, ws, bs, d):
     import torch.nn.functional as F
