@@ -298,23 +298,23 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
         }
         return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);
     }
-    int IBLK, JBLK, cfg;
-    if (!vec) { IBLK = 32; JBLK = 32; cfg = 7; }
+    int IBLK, JBLK, cfg, PM = 32;
+    if (!vec) { IBLK = 32; JBLK = 32; cfg = 7; PM = 64; }
     else if (d.K > 64 && d.Nout > 64) { IBLK = 128; JBLK = 128; cfg = 0; }
     else if (d.K > 64 && d.Nout > 32) { IBLK = 128; JBLK = 64; cfg = 1; }
     else if (d.K > 32 && d.Nout > 64) { IBLK = 64; JBLK = 128; cfg = 2; }
     else if (d.K > 32 && d.Nout > 32) { IBLK = 64; JBLK = 64; cfg = 3; }
-    else if (d.K <= 32 && d.Nout > 32) { IBLK = 32; JBLK = 64; cfg = 4; }
-    else if (d.K > 32) { IBLK = 64; JBLK = 32; cfg = 5; }
-    else { IBLK = 32; JBLK = 32; cfg = 6; }
+    else if (d.K <= 32 && d.Nout > 32) { IBLK = 32; JBLK = 64; cfg = 4; PM = 128; }
+    else if (d.K > 32) { IBLK = 64; JBLK = 32; cfg = 5; PM = 128; }
+    else { IBLK = 32; JBLK = 32; cfg = 6; PM = 64; }
     const int itiles = (d.K + IBLK - 1) / IBLK, jtiles = (d.Nout + JBLK - 1) / JBLK;
     const int tiles = d.ntaps * itiles * jtiles;
     const size_t slab = (size_t)d.ntaps * d.K * d.Nout + (size_t)d.ntaps * d.Nout;
-    // Pixels are split in slabs of `spb` 32-pixel steps.  Blocks are dealt round-robin over the
+    // Pixels are split in slabs of `spb` PM-pixel steps.  Blocks are dealt round-robin over the
     // 256 CUs and co-resident blocks share the MFMA pipe, so the kernel lasts as long as the CU
     // with the most blocks; every slab costs one write and one read of the partial tile.
-    const long long steps = (M + 31) / 32;
-    const double t_step = (IBLK / 64.0) * (JBLK / 64.0) * 0.43;       // us of one block step on a shared pipe
+    const long long steps = (M + PM - 1) / PM;
+    const double t_step = (IBLK / 64.0) * (JBLK / 64.0) * 0.43 * (PM / 32);   // us of one block step on a shared pipe
     const double slab_us = slab * sizeof(float) * 2 / 4.0e6;         // write + read at ~4 TB/s
     static int forced_spb = -1;
     if (forced_spb < 0) { const char *e = getenv("ERFNET_WGRAD_SPB"); forced_spb = e ? atoi(e) : 0; }
@@ -328,7 +328,7 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
         if (t < best) { best = t; best_spb = spb; }
     }
     if (forced_spb > 0) best_spb = forced_spb < steps ? forced_spb : steps;
-    const long long sp = best_spb * 32;
+    const long long sp = best_spb * PM;
     const long long nsplit = (M + sp - 1) / sp;
     WgradBatch wb;
     memset(&wb, 0, sizeof(wb));
@@ -348,10 +348,10 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
     case 1: wgrad_f32_kernel<2, 1, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
     case 2: wgrad_f32_kernel<1, 2, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
     case 3: wgrad_f32_kernel<1, 1, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
-    case 4: wgrad_f32_kernel<1, 1, 1, 2, true><<<grid, 128, 0, st>>>(wb); break;
-    case 5: wgrad_f32_kernel<1, 1, 2, 1, true><<<grid, 128, 0, st>>>(wb); break;
-    case 6: wgrad_f32_kernel<1, 1, 1, 1, true><<<grid, 64, 0, st>>>(wb); break;
-    default: wgrad_f32_kernel<1, 1, 1, 1, false><<<grid, 64, 0, st>>>(wb); break;
+    case 4: wgrad_f32_kernel<1, 1, 1, 2, true, 128><<<grid, 128, 0, st>>>(wb); break;
+    case 5: wgrad_f32_kernel<1, 1, 2, 1, true, 128><<<grid, 128, 0, st>>>(wb); break;
+    case 6: wgrad_f32_kernel<1, 1, 1, 1, true, 64><<<grid, 64, 0, st>>>(wb); break;
+    default: wgrad_f32_kernel<1, 1, 1, 1, false, 64><<<grid, 64, 0, st>>>(wb); break;
     }
     CHECK_LAUNCH("wgrad_f32_kernel");
     return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);

@@ -289,14 +289,16 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 // ------------------------------------------------------------------------------------------------
 // Weight gradient.  Block tile: IBLK = GI*IB*32 input channels x JBLK = GJ*JB*32 output channels of
 // one tap; blockIdx.x = pixel slab, blockIdx.y = (tap, i-tile, j-tile).
-// LDS: X tile [32 pixels][IBLK], G tile [32 pixels][JBLK]; MFMA operands are read with ds_read_b32
-// (lanes walk the channel, the two lane halves take pixel 2s and 2s+1).
-template <int IB, int JB, int GI, int GJ, bool VEC>
+// LDS: X tile [PM pixels][IBLK], G tile [PM pixels][JBLK]; MFMA operands are read with ds_read_b32
+// (lanes walk the channel, the two lane halves take pixel 2s and 2s+1).  PM = pixels per step:
+// 32 for the large tiles; the small-channel tiles take 64-128 so that a step carries enough MFMAs
+// for its two barriers.
+template <int IB, int JB, int GI, int GJ, bool VEC, int PM = 32>
 __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradBatch batch)
 {
     const WgradDesc &d = batch.d[blockIdx.z];      // up to four convolutions per launch
     constexpr int IBLK = GI * IB * 32, JBLK = GJ * JB * 32, NT = GI * GJ * 64;
-    constexpr int PM = 32;
+    static_assert(PM <= GI * GJ * 64 && PM % 32 == 0, "one thread per pixel of a step keeps the pixel table");
     constexpr int XV = PM * IBLK / 4, GV = PM * JBLK / 4;        // float4 slots per tile
     constexpr int XP = (XV + NT - 1) / NT, GP = (GV + NT - 1) / NT;
     constexpr int XPITCH = IBLK, GPITCH = JBLK;
