@@ -183,9 +183,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get("ERFNET_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {world}; using {world}", file=sys.stderr)
+    local_rank %= max(torch.cuda.device_count(), 1)     # rehearsals with more ranks than GPUs share devices
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
