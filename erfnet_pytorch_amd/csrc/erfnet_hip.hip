@@ -1050,7 +1050,8 @@ int erf_cross_entropy_forward(const float *logits, const long long *target, floa
     float *partial = ar.floats((size_t)blocks * 2);
     if (!partial) return fail("cross entropy: workspace too small");
     CeDesc d = {logits, target, lse, partial, P, H * W, K, ignore_index};
-    ce_fwd_kernel<<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
+    if (K <= CE_MAX_K) ce_fwd_kernel<true><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
+    else ce_fwd_kernel<false><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     CHECK_LAUNCH("ce_fwd_kernel");
     ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
     CHECK_LAUNCH("ce_reduce_kernel");

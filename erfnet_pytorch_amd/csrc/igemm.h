@@ -231,9 +231,16 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
         __syncthreads();
     };
 
-    load_step(0, st0);
-    store_step(0, st0);
-    if (nsteps > 1) load_step(1, st0);
+    // Prologue: the loads of the first two steps are in flight together (the second set of staging
+    // registers is free here, the accumulators are not live yet), so only one memory latency is
+    // exposed before the first MFMA.
+    {
+        Stage st1;
+        load_step(0, st0);
+        if (nsteps > 1) load_step(1, st1);
+        store_step(0, st0);
+        if (nsteps > 1) st0 = st1;
+    }
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) k_step(s, st0);
 

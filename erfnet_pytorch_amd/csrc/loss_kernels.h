@@ -9,6 +9,7 @@
 #include "common.h"
 
 #define CE_BLOCK 256
+#define CE_MAX_K 32
 
 struct CeDesc {
     const float *logits;        // [N][K][HW]
@@ -20,6 +21,7 @@ struct CeDesc {
     long long ignore_index;
 };
 
+template <bool SMALL_K>
 __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const CeDesc d)
 {
     __shared__ float red[2][CE_BLOCK / 64];
@@ -29,11 +31,27 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const CeDesc d)
         const long long n = p / d.HW;
         const float *x = d.logits + n * (long long)d.K * d.HW + (p - n * d.HW);
         const long long t = d.target[p];
-        float m = -INFINITY;
-        for (int k = 0; k < d.K; ++k) m = fmaxf(m, x[(long long)k * d.HW]);
-        float s = 0.0f;
-        for (int k = 0; k < d.K; ++k) s += __expf(x[(long long)k * d.HW] - m);
-        const float lse = m + __logf(s);
+        float lse;
+        if (SMALL_K) {
+            // one pass over the logits: the class values stay in registers.  Slots beyond K repeat
+            // the last class (unconditional loads; harmless for the max, left out of the sum).
+            float v[CE_MAX_K];
+#pragma unroll
+            for (int k = 0; k < CE_MAX_K; ++k) v[k] = x[(long long)(k < d.K ? k : d.K - 1) * d.HW];
+            float m = v[0];
+#pragma unroll
+            for (int k = 1; k < CE_MAX_K; ++k) m = fmaxf(m, v[k]);
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < CE_MAX_K; ++k) s += k < d.K ? __expf(v[k] - m) : 0.0f;
+            lse = m + __logf(s);
+        } else {
+            float m = -INFINITY;
+            for (int k = 0; k < d.K; ++k) m = fmaxf(m, x[(long long)k * d.HW]);
+            float s = 0.0f;
+            for (int k = 0; k < d.K; ++k) s += __expf(x[(long long)k * d.HW] - m);
+            lse = m + __logf(s);
+        }
         d.lse[p] = lse;
         if (t != d.ignore_index && t >= 0 && t < d.K) {
             loss = lse - x[t * d.HW];

@@ -367,7 +367,8 @@ def test_direct_gradient_write_matches_autograd_accumulation():
             assert torch.equal(a[k], b[k]), (step, k)
 
 
-@pytest.mark.parametrize("shape,k", [((2, 64, 128), 20), ((1, 7, 13), 1), ((3, 33, 17), 5)])
+@pytest.mark.parametrize("shape,k", [((2, 64, 128), 20), ((1, 7, 13), 1), ((3, 33, 17), 5), ((1, 9, 11), 32),
+                                     ((1, 9, 11), 40)])
 def test_cross_entropy_against_torch_and_oracle(shape, k):
     """CrossEntropyLoss2d (train/evaluation_functions.py:6-14): loss and gradient of the HIP kernels
     against the oracle's float64 restatement and torch's own op on the same tensors."""
