@@ -4,6 +4,7 @@
 #include "aux_kernels.h"
 #include "igemm.h"
 #include "stream16.h"
+#include "sampler16.h"
 #include "loss_kernels.h"
 
 #include <atomic>
@@ -365,6 +366,86 @@ int launch_wgrad(WgradDesc &d, float *dw, float *db, const int *woff, int wsk, i
     return launch_wgrad_batch(&d, 1, dws, dbs, woff, wsk, wsn, bias_taps, ar, st);
 }
 
+// ------------------------------------------------------------------ 16-channel sampler layers
+// sampler16.h pairs a coarse grid (K = 16, 32, 48 or 64 channels) with a fine grid of 16 channels.
+bool sampler16_shape_ok(int K, long long coarse_pixels, int coarse_C, int fine_C)
+{
+    if (!stream16_enabled()) return false;
+    if (K % 16 || K < 16 || K > 64) return false;
+    return coarse_pixels * coarse_C < (1LL << 29) && coarse_pixels * 4 * fine_C < (1LL << 29);
+}
+
+// fine = epi(transposed 3x3 stride-2 convolution of coarse).  d: GH x GW = coarse grid, in = coarse,
+// out = fine (16 channels at out_coff), w indexed woff = kh*3+kw, wsk (coarse channel), wsn (fine).
+bool up16_fwd_ok(const IgemmDesc &d)
+{
+    if (d.Nout != 16 || d.epi.nscale) return false;
+    if (!sampler16_shape_ok(d.K, (long long)d.N * d.GH * d.GW, d.in_C, d.out_C)) return false;
+    if (d.in_C % 4 || d.in_coff % 4 || d.out_C % 4 || d.out_coff % 4 || !aligned16(d.in) || !aligned16(d.out)) return false;
+    if (d.epi.res && (d.epi.res_C % 4 || d.epi.res_coff % 4 || !aligned16(d.epi.res) ||
+                      (long long)d.N * d.GH * d.GW * 4 * d.epi.res_C >= (1LL << 29))) return false;
+    if (d.epi.mask && (d.epi.mask_C % 4 || d.epi.mask_coff % 4 || !aligned16(d.epi.mask) ||
+                       (long long)d.N * d.GH * d.GW * 4 * d.epi.mask_C >= (1LL << 29))) return false;
+    if (d.epi.bias && !aligned16(d.epi.bias)) return false;
+    if (d.epi.bn.on && (!d.epi.bn.gamma || !d.epi.bn.beta || !aligned16(d.epi.bn.gamma) || !aligned16(d.epi.bn.beta) ||
+                        !aligned16(d.epi.bn.mean) || !aligned16(d.epi.bn.var))) return false;
+    return true;
+}
+int launch_up16_fwd(const IgemmDesc &d, hipStream_t st)
+{
+    const long long M = (long long)d.N * d.GH * d.GW;
+    if (M == 0) return 0;
+    long long blocks = (M + 63) / 64;             // one 16-position tile per wave at least
+    if (blocks > 768) blocks = 768;               // three resident blocks per CU share the weight fill
+    switch (d.K / 16) {
+    case 1: up16_fwd_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+    case 2: up16_fwd_kernel<2><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+    case 3: up16_fwd_kernel<3><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+    default: up16_fwd_kernel<4><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+    }
+    CHECK_LAUNCH("up16_fwd_kernel");
+    return 0;
+}
+
+// Weight gradient of either layer.  d: GH x GW = coarse grid, in = coarse tensor (K channels at
+// in_coff of in_C), g = fine tensor (16 channels at g_coff of g_C).  dw[woff = kh*3+kw + k*wsk + j*wsn];
+// the bias gradient is the sum of the fine tensor (kside = 0) or of the coarse tensor (kside = 1).
+int launch_up16_wgrad(WgradDesc &d, float *dw, float *db, int wsk, int wsn, int kside, Arena &ar, hipStream_t st)
+{
+    const long long M = (long long)d.N * d.GH * d.GW;
+    const int KQ = d.K / 16;
+    const size_t slab = (size_t)9 * d.K * 16 + 9 * 16 + d.K;
+    long long nsplit = (M + 255) / 256;           // 64 positions per wave at least
+    if (nsplit > 512) nsplit = 512;
+    if (nsplit < 1) nsplit = 1;
+    long long sp = (M + nsplit - 1) / nsplit;
+    sp = (sp + 15) / 16 * 16;
+    nsplit = (M + sp - 1) / sp;
+    d.nsplit = (int)nsplit;
+    d.split_pixels = (int)sp;
+    d.ntaps = 9; d.Nout = 16;
+    d.partial = ar.floats(slab * nsplit);
+    if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
+    switch (KQ) {
+    case 1: up16_wgrad_kernel<1><<<(unsigned)nsplit, 256, 0, st>>>(d); break;
+    case 2: up16_wgrad_kernel<2><<<(unsigned)nsplit, 256, 0, st>>>(d); break;
+    case 3: up16_wgrad_kernel<3><<<(unsigned)nsplit, 256, 0, st>>>(d); break;
+    default: up16_wgrad_kernel<4><<<(unsigned)nsplit, 256, 0, st>>>(d); break;
+    }
+    CHECK_LAUNCH("up16_wgrad_kernel");
+    ReduceBatch rb;
+    memset(&rb, 0, sizeof(rb));
+    ReduceDesc &r = rb.r[0];
+    r.partial = d.partial; r.dw = dw; r.db = db;
+    r.nsplit = d.nsplit; r.ntaps = 9; r.K = d.K; r.Nout = 16;
+    for (int t = 0; t < 9; ++t) r.woff[t] = t;
+    r.wsk = wsk; r.wsn = wsn; r.bias_taps = 1u; r.tail = d.K; r.kside = kside;
+    const long long tot = (long long)9 * d.K * 16 + (kside ? d.K : 16);
+    reduce_partials_kernel<<<dim3((unsigned)((tot + 31) / 32), 1, 1), 256, 0, st>>>(rb);
+    CHECK_LAUNCH("reduce_partials_kernel");
+    return 0;
+}
+
 unsigned grid_for(long long work_items, int per_block = 256, unsigned cap = 8192)
 {
     long long g = (work_items + per_block - 1) / per_block;
@@ -638,7 +719,16 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         int woff[9];
         for (int t = 0; t < 9; ++t) { d.tdh[t] = t / 3 - 1; d.tdw[t] = t % 3 - 1; woff[t] = t; }
         d.g_H = Ho; d.g_W = Wo; d.g_C = Cout; d.Nout = Cc;
-        if (launch_wgrad(d, dw, db, woff, 9, Cin * 9, 1u, ar, st)) return 1;
+        const bool x_nhwc = sc == 1 && sw == Cin && sh == (long long)W * Cin && sn == (long long)H * W * Cin;
+        if (Cin == 16 && x_nhwc && sampler16_shape_ok(Cc, Mo, Cout, Cin)) {
+            // coarse side = the gradient of the convolution output, fine side = the block input
+            WgradDesc e;
+            memset(&e, 0, sizeof(e));
+            e.in = g; e.in_C = Cout; e.K = Cc;
+            e.g = x; e.g_C = Cin;
+            e.N = N; e.GH = Ho; e.GW = Wo;
+            if (launch_up16_wgrad(e, dw, db, Cin * 9, 9, 1, ar, st)) return 1;
+        } else if (launch_wgrad(d, dw, db, woff, 9, Cin * 9, 1u, ar, st)) return 1;
     }
     if (dx) {
         // dx is NHWC [N,H,W,Cin]: max-pool gradient first, then the conv data gradient on top.
@@ -663,7 +753,9 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         }
         for (int t = 0; t < 9; ++t) { d.tdh[t] = pt.dh[t]; d.tdw[t] = pt.dw[t]; d.woff[t] = pt.kh[t] * 3 + pt.kw[t]; }
         d.wsk = Cin * 9; d.wsn = 9;   // W[co][ci][kh][kw]: k = co, j = ci
-        if (launch_igemm(d, ar, st)) return 1;
+        if (up16_fwd_ok(d)) {
+            if (launch_up16_fwd(d, st)) return 1;
+        } else if (launch_igemm(d, ar, st)) return 1;
     }
     return 0;
 }
@@ -854,7 +946,9 @@ int erf_upsampler_forward(const float *x, const float *w, const float *b, const 
     }
     for (int t = 0; t < 9; ++t) { d.tdh[t] = pt.dh[t]; d.tdw[t] = pt.dw[t]; d.woff[t] = pt.kh[t] * 3 + pt.kw[t]; }
     d.wsk = Cout * 9; d.wsn = 9;       // W[ci][co][kh][kw]: k = ci, j = co
-    if (launch_igemm(d, ar, st)) return 1;
+    if (up16_fwd_ok(d)) {              // 16 output channels: streaming kernel, all parity classes per wave
+        if (launch_up16_fwd(d, st)) return 1;
+    } else if (launch_igemm(d, ar, st)) return 1;
     if (two_pass) {
         if (mode == 2) { if (bn_train_stats(bn, dst, Mo, Cout, ar, st)) return 1; }
         else if (bn_eval_prepare(bn, Cout, st)) return 1;
@@ -901,7 +995,9 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
             woff[t] = pt.kh[t] * 3 + pt.kw[t];
         }
         d.g_H = 2 * H; d.g_W = 2 * W; d.g_C = Cout; d.Nout = Cout;
-        if (launch_wgrad(d, dw, db, woff, Cout * 9, 9, pt.rep_mask, ar, st)) return 1;
+        if (Cout == 16 && sampler16_shape_ok(Cin, (long long)N * H * W, Cin, Cout)) {
+            if (launch_up16_wgrad(d, dw, db, Cout * 9, 9, 0, ar, st)) return 1;
+        } else if (launch_wgrad(d, dw, db, woff, Cout * 9, 9, pt.rep_mask, ar, st)) return 1;
     }
     if (dx) {   // data gradient = ordinary 3x3 stride-2 convolution of g
         IgemmDesc d;

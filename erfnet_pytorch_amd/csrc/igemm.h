@@ -485,41 +485,50 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradBatch
 
 // dst[woff[t] + k*wsk + j*wsn] = sum_s partial[s][t][k][j];
 // db[j] = sum_s sum_{t in bias_taps} partial[s][bias row t][j]   (fixed order: reproducible).
+// A slab may carry K more sums behind the bias rows (column sums of the k-side operand); with
+// kside != 0 those, not the bias rows, are the bias gradient: db[k] = sum_s partial[s][tail k].
 struct ReduceDesc {
     const float *partial;
     float *dw, *db;
     int nsplit, ntaps, K, Nout;
     int woff[ERF_MAX_TAPS], wsk, wsn;
     unsigned bias_taps;
+    int tail, kside;        // tail = floats behind the bias rows in a slab (0 or K)
 };
 
-// Block = 32 consecutive slab elements x 8 slab groups: thread (g, e) sums slabs g, g+8, ... of
-// element e, the 8 group sums are then added in a fixed order through LDS.
 struct ReduceBatch {
     ReduceDesc r[ERF_WGRAD_BATCH];
 };
 
+// Block = 32 consecutive slab elements x 8 slab groups: thread (g, e) sums slabs g, g+8, ... of
+// element e, the 8 group sums are then added in a fixed order through LDS.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceBatch batch)
 {
     const ReduceDesc &d = batch.r[blockIdx.y];
     __shared__ float red[8][33];
     const long long nw = (long long)d.ntaps * d.K * d.Nout;
-    const long long slab = nw + (long long)d.ntaps * d.Nout;
+    const long long slab = nw + (long long)d.ntaps * d.Nout + d.tail;
+    const int nb = d.kside ? d.K : d.Nout;                      // bias elements
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const long long idx = (long long)blockIdx.x * 32 + e;
     float s = 0.0f;
     if (idx < nw) {
         for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + idx];
-    } else if (idx < nw + d.Nout) {
+    } else if (idx < nw + nb) {
         const int j = (int)(idx - nw);
-        for (int t = 0; t < d.ntaps; ++t) {
-            if (!((d.bias_taps >> t) & 1u)) continue;
-            for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + nw + (long long)t * d.Nout + j];
+        if (d.kside) {
+            const long long off = nw + (long long)d.ntaps * d.Nout + j;
+            for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + off];
+        } else {
+            for (int t = 0; t < d.ntaps; ++t) {
+                if (!((d.bias_taps >> t) & 1u)) continue;
+                for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + nw + (long long)t * d.Nout + j];
+            }
         }
     }
     red[g][e] = s;
     __syncthreads();
-    if (g != 0 || idx >= nw + d.Nout) return;
+    if (g != 0 || idx >= nw + nb) return;
     float tot = red[0][e];
 #pragma unroll
     for (int k = 1; k < 8; ++k) tot += red[k][e];

@@ -1,0 +1,240 @@
+// The stride-2 3x3 layers between the 16-channel full-resolution stage and the 64-channel stage
+// (UpsamplerBlock 64->16 forward, DownsamplerBlock 16->64 data gradient, and the weight gradients
+// of both) as streaming kernels on v_mfma_f32_16x16x4_f32.
+//
+// All four are the same pairing of a coarse grid (H x W, K = 16*KQ channels) with a fine grid
+// (2H x 2W, 16 channels): coarse pixel (i+dh, j+dw) meets fine pixel (2i+a, 2j+b) through tap
+// (kh, kw), where per axis (a, kh, dh) is one of (0,1,0), (1,0,1), (1,2,0).  Nine taps, four fine
+// "classes" (a,b), four coarse "sources" (dh,dw) per coarse position.  With 16 channels on the
+// fine side the generic 32x32 MFMA tile would be half padding and every output pixel would be
+// written as a 64-byte piece by a different block; here one wave owns 16 (forward) or 4 (weight
+// gradient) coarse positions with all their classes.
+//
+// MFMA 16x16x4 layouts (lane l: i = l & 15, g = l >> 4):
+//   A[16][4]: lane holds A[i][g];  B[4][16]: lane holds B[g][i];  D[16][16]: reg r = D[4g + r][i].
+#pragma once
+#include "common.h"
+
+#define S16_TAP_KH(t) ((t) / 3)
+#define S16_TAP_KW(t) ((t) % 3)
+#define S16_CLASS(t) (((S16_TAP_KH(t) == 1 ? 0 : 1) << 1) | (S16_TAP_KW(t) == 1 ? 0 : 1))
+#define S16_SRC(t) (((S16_TAP_KH(t) == 0 ? 1 : 0) << 1) | (S16_TAP_KW(t) == 0 ? 1 : 0))
+
+// fine[2i+a][2j+b][c] = epi( sum_taps sum_k coarse[i+dh][j+dw][k] * W[tap][k][c] ),  c < 16.
+// Computed transposed (D[c][pos] = Wt * X) so that a lane ends up with four consecutive channels
+// of one fine pixel per class: 16-byte loads and stores throughout.  The weights of all nine taps
+// sit in LDS as [tap][k/16][c][16 k]: a wave's ds_read_b128 covers 1 KiB contiguous (no conflicts).
+// A lane loads channels 16q+4g..+3 of its coarse source pixels; MFMA number m takes element m, so
+// the instruction's k index g stands for channel 16q + 4g + m on both operands.
+template <int KQ>
+__global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
+{
+    __shared__ __attribute__((aligned(16))) float Wl[9 * KQ * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    for (int idx = tid; idx < 9 * KQ * 256; idx += 256) {
+        const int kk = idx & 15, j = (idx >> 4) & 15, q = (idx >> 8) % KQ, t = idx / (KQ * 256);
+        Wl[idx] = d.w[t + (long long)(16 * q + kk) * d.wsk + (long long)j * d.wsn];
+    }
+    __syncthreads();
+
+    const unsigned H = (unsigned)d.GH, W = (unsigned)d.GW, M = (unsigned)d.N * H * W, HW = H * W;
+    const unsigned Pout = M * 4u;
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, M * d.in_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, Pout * d.out_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
+    const bool has_mask = d.epi.mask != nullptr, relu = d.epi.relu != 0;
+
+    // channel affine of the lane's four output channels 4g..4g+3: v * sc + sh
+    f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    f32x4 sh = buf_load4(r_bias, g * 16u);
+    if (d.epi.bn.on) {          // wave-uniform
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(d.epi.bn.gamma + 4 * g);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(d.epi.bn.beta + 4 * g);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(d.epi.bn.mean + 4 * g);
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(d.epi.bn.var + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = d.epi.bn.var_is_invstd ? va[r] : rsqrtf(va[r] + d.epi.bn.eps);
+            sc[r] = ga[r] * inv;
+            sh[r] = (sh[r] - mu[r]) * sc[r] + be[r];
+        }
+    }
+
+    const unsigned ntiles = (M + 15) / 16;
+    for (unsigned tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const unsigned p = tile * 16 + i;
+        const bool valid = p < M;
+        const unsigned pp = valid ? p : 0;
+        const unsigned n = pp / HW, rem = pp - n * HW;
+        const unsigned y = rem / W, x = rem - y * W;
+        f32x4 xs[4][KQ];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned ys = y + (s >> 1), xx = x + (s & 1);
+            const bool ok = valid && ys < H && xx < W;
+            const unsigned off = (((n * H + ys) * W + xx) * d.in_C + d.in_coff + 4 * g) * 4u;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) xs[s][q] = buf_load4(r_in, ok ? off + q * 64u : ERF_OOB);
+        }
+        // epilogue operands of the four fine pixels
+        unsigned ooff[4];
+        f32x4 rres[4], rmask[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
+            ooff[c] = valid ? (px * d.out_C + d.out_coff + 4 * g) * 4u : ERF_OOB;
+            rres[c] = buf_load4(r_res, valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) * 4u : ERF_OOB);
+            rmask[c] = buf_load4(r_mask, valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) * 4u : ERF_OOB);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) {
+            f32x4 wf[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                wf[t] = *reinterpret_cast<const f32x4 *>(&Wl[((t * KQ + q) * 16 + i) * 16 + 4 * g]);
+            // taps innermost: consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    acc[S16_CLASS(t)] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][m], xs[S16_SRC(t)][q][m],
+                                                                             acc[S16_CLASS(t)], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = acc[c][r] * sc[r] + sh[r] + rres[c][r];
+                if (relu) e = fmaxf(e, 0.0f);
+                v[r] = (!has_mask || rmask[c][r] > 0.0f) ? e : 0.0f;
+            }
+            buf_store4(r_out, ooff[c], v);
+        }
+    }
+}
+
+// dW[tap][k][j] = sum_pos coarse[pos + d(tap)][k] * fine[2 pos + class(tap)][j]   (k < 16*KQ, j < 16)
+// MFMA roles: row = k within its 16-channel quad, contraction = 4 consecutive coarse positions,
+// column = j.  Lane (i, g) reads one float per source/class of position 4u + g.  Each wave keeps
+// 9*KQ accumulators over its range of positions; the four waves of a block add them up in LDS in
+// a fixed order and the block writes one slab:
+//   [9][K][16] weight partials, [9][16] bias rows (row 0 = sum of the fine tensor, rest zero),
+//   [K] sums of the coarse tensor (the bias gradient when the coarse side is the convolution output).
+template <int KQ>
+__global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
+{
+    constexpr int NACC = 9 * KQ, NW_ = NACC * 256, SLOTS = NW_ + 16 + 16 * KQ;
+    __shared__ float red[SLOTS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned H = (unsigned)d.GH, W = (unsigned)d.GW, M = (unsigned)d.N * H * W, HW = H * W;
+    const unsigned wsp = (unsigned)d.split_pixels / 4;            // multiple of 4 (host)
+    const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
+    unsigned wend = wbeg + wsp;
+    if (wend > M) wend = M;
+    const __amdgpu_buffer_rsrc_t r_c = make_rsrc(d.in, M * d.in_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_f = make_rsrc(d.g, M * 4u * d.g_C * 4u);
+
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float fsum = 0.0f, csum[KQ];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) csum[q] = 0.0f;
+
+    struct Frag {
+        float cs[4][KQ], fc[4];
+    };
+    auto load_group = [&](unsigned m0, Frag &f) {
+        const unsigned p = m0 + g;
+        const bool valid = p < wend;
+        const unsigned pp = valid ? p : 0;
+        const unsigned n = pp / HW, rem = pp - n * HW;
+        const unsigned y = rem / W, x = rem - y * W;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned ys = y + (s >> 1), xx = x + (s & 1);
+            const bool ok = valid && ys < H && xx < W;
+            const unsigned off = (((n * H + ys) * W + xx) * d.in_C + d.in_coff + i) * 4u;
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) f.cs[s][q] = buf_load1(r_c, ok ? off + q * 64u : ERF_OOB);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
+            f.fc[c] = buf_load1(r_f, valid ? (px * d.g_C + d.g_coff + i) * 4u : ERF_OOB);
+        }
+    };
+    auto mfma_group = [&](const Frag &f) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fsum += f.fc[c];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) csum[q] += f.cs[0][q];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int q = 0; q < KQ; ++q)
+                acc[t * KQ + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.cs[S16_SRC(t)][q], f.fc[S16_CLASS(t)],
+                                                                       acc[t * KQ + q], 0, 0, 0);
+    };
+
+    // two register sets: the loads of the next four positions are in flight during the MFMAs
+    Frag fa, fb;
+    if (wbeg < wend) load_group(wbeg, fa);
+    for (unsigned m0 = wbeg; m0 < wend; m0 += 8) {
+        if (m0 + 4 < wend) load_group(m0 + 4, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_group(fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m0 + 8 < wend) load_group(m0 + 8, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        if (m0 + 4 < wend) mfma_group(fb);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // sums over the position index g held by the four lane groups
+    fsum += __shfl_xor(fsum, 16);
+    fsum += __shfl_xor(fsum, 32);
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+        csum[q] += __shfl_xor(csum[q], 16);
+        csum[q] += __shfl_xor(csum[q], 32);
+    }
+    // block reduction: the waves add into LDS one after the other (fixed order)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // accumulator a = tap*KQ + q holds rows k = 16q + 4g + r, column j = i
+                    const int e = ((a / KQ) * 16 * KQ + (a % KQ) * 16 + 4 * g + r) * 16 + i;
+                    red[e] = (w ? red[e] : 0.0f) + acc[a][r];
+                }
+            if (g == 0) {
+                red[NW_ + i] = (w ? red[NW_ + i] : 0.0f) + fsum;
+#pragma unroll
+                for (int q = 0; q < KQ; ++q) red[NW_ + 16 + 16 * q + i] = (w ? red[NW_ + 16 + 16 * q + i] : 0.0f) + csum[q];
+            }
+        }
+        __syncthreads();
+    }
+    // slab: weights, 9 bias rows (row 0 carries the fine-side sums), coarse-side sums
+    const int slab = NW_ + 9 * 16 + 16 * KQ;
+    float *P = d.partial + (long long)blockIdx.x * slab;
+    for (int e = tid; e < slab; e += 256) {
+        float v;
+        if (e < NW_) v = red[e];
+        else if (e < NW_ + 16) v = red[e];
+        else if (e < NW_ + 9 * 16) v = 0.0f;
+        else v = red[NW_ + 16 + (e - NW_ - 9 * 16)];
+        P[e] = v;
+    }
+}
