@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
     }
 }
 
-// Weight/bias gradient of the above: thread (co, e) of a block accumulates
-// sum_pix g[pix][co] * patch[pix][e] over the block's pixel slab, from LDS tiles.
+// Weight/bias gradient of the above: dW[co][e] = sum_pix g[pix][co] * patch[pix][e] over the block's
+// pixel slab (Cc <= 16).
 struct FirstDownWgradDesc {
     const float *x;
     long long sn, sc, sh, sw;
@@ -82,57 +82,79 @@ struct FirstDownWgradDesc {
     float *partial;      // [nsplit][Cc*27 + Cc]
     int N, H, W, Cc, g_C;
     int split_pixels;
+    unsigned x_bytes;    // extent of x covered by its strides
 };
 
-__global__ __launch_bounds__(512) void first_down_wgrad_kernel(const FirstDownWgradDesc d)
+// MFMA 16x16x4: row = conv channel co, contraction = 4 consecutive output pixels, column = patch
+// element e (27 taps*channels, column 27 = 1 for the bias; two column tiles).  Lane (i, g) reads
+// g[pix g][co = i] and the two patch elements e = i, 16 + i of pixel g straight from global memory
+// (buffer loads: out-of-image taps, pixels beyond the slab and padding columns read zero).  Each
+// wave covers a quarter of the block's pixel slab; the four waves are summed through LDS.
+__global__ __launch_bounds__(256) void first_down_wgrad_kernel(const FirstDownWgradDesc d)
 {
-    constexpr int PT = 64;     // pixels per LDS tile
-    __shared__ float patch[PT * 28];
-    __shared__ float gt[PT * 16];   // Cc <= 16 per pass
-    const int Ho = d.H / 2, Wo = d.W / 2;
-    const long long M = (long long)d.N * Ho * Wo;
-    const long long mbeg = (long long)blockIdx.x * d.split_pixels;
-    long long mend = mbeg + d.split_pixels;
-    if (mend > M) mend = M;
-    const int tid = threadIdx.x;
-    const int co = tid / 28, e = tid % 28;   // 16 x 28 = 448 active threads
-    const bool active = co < d.Cc && co < 16;
-    float acc = 0.0f;
-    for (long long mb = mbeg; mb < mend; mb += PT) {
-        for (int i = tid; i < PT * 28; i += 512) {
-            const int p = i / 28, q = i % 28;
-            const long long m = mb + p;
-            float v = 0.0f;
-            if (m < mend) {
-                if (q == 27) v = 1.0f;     // bias column
-                else {
-                    const int n = (int)(m / (Ho * Wo));
-                    const int rem = (int)(m - (long long)n * Ho * Wo);
-                    const int oh = rem / Wo, ow = rem - oh * Wo;
-                    const int ci = q / 9, kh = (q % 9) / 3, kw = q % 3;
-                    const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
-                    if (ih >= 0 && iw >= 0 && ih < d.H && iw < d.W)
-                        v = d.x[n * d.sn + ci * d.sc + ih * d.sh + iw * d.sw];
-                }
-            }
-            patch[i] = v;
-        }
-        for (int i = tid; i < PT * 16; i += 512) {
-            const int p = i / 16, c = i % 16;
-            const long long m = mb + p;
-            gt[i] = (m < mend && c < d.Cc) ? d.g[m * d.g_C + c] : 0.0f;
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll 8
-            for (int p = 0; p < PT; ++p) acc = fmaf(gt[p * 16 + co], patch[p * 28 + e], acc);
-        }
-        __syncthreads();
+    __shared__ float red[4][16 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned Ho = d.H / 2, Wo = d.W / 2, HWo = Ho * Wo, M = (unsigned)d.N * HWo;
+    const unsigned wsp = (unsigned)d.split_pixels / 4;                 // multiple of 4 (host)
+    const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
+    unsigned wend = wbeg + wsp;
+    if (wend > M) wend = M;
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x, d.x_bytes);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, M * d.g_C * 4u);
+    // this lane's two patch elements: e -> (ci, kh, kw); e = 27 is the bias column, e > 27 padding
+    int eci[2], ekh[2], ekw[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const int e = 16 * T + i;
+        eci[T] = e / 9; ekh[T] = (e % 9) / 3; ekw[T] = e % 3;
     }
-    if (active) {
-        float *P = d.partial + (long long)blockIdx.x * (d.Cc * 27 + d.Cc);
-        if (e < 27) P[co * 27 + e] = acc;
-        else P[d.Cc * 27 + co] = acc;
+    const bool bias_lane = i == 11;            // e = 27 in the second tile
+    f32x4 acc[2];
+    acc[0] = acc[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    struct Frag { float gv, pv[2]; };
+    auto load_group = [&](unsigned m0, Frag &f) {
+        const unsigned m = m0 + g;
+        const bool valid = m < wend;
+        const unsigned mm = valid ? m : 0;
+        const unsigned n = mm / HWo, rem = mm - n * HWo;
+        const unsigned oh = rem / Wo, ow = rem - oh * Wo;
+        f.gv = buf_load1(r_g, (valid && i < d.Cc) ? (mm * d.g_C + i) * 4u : ERF_OOB);
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+            const int ih = 2 * (int)oh - 1 + ekh[T], iw = 2 * (int)ow - 1 + ekw[T];
+            const bool ok = valid && 16 * T + i < 27 && ih >= 0 && iw >= 0 && ih < d.H && iw < d.W;
+            const long long off = (long long)n * d.sn + eci[T] * d.sc + ih * d.sh + iw * d.sw;
+            f.pv[T] = buf_load1(r_x, ok ? (unsigned)off * 4u : ERF_OOB);
+        }
+        if (bias_lane) f.pv[1] = valid ? 1.0f : 0.0f;
+    };
+    auto mfma_group = [&](const Frag &f) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T) acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.gv, f.pv[T], acc[T], 0, 0, 0);
+    };
+    // four groups in flight
+    for (unsigned m0 = wbeg; m0 < wend; m0 += 16) {
+        Frag f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_group(m0 + 4 * u, f[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mfma_group(f[u]);
+    }
+    // D[row = co = 4g + r][col = e = 16T + i]
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(4 * g + r) * 32 + 16 * T + i] = acc[T][r];
+    __syncthreads();
+    float *P = d.partial + (long long)blockIdx.x * (d.Cc * 27 + d.Cc);
+    for (int idx = tid; idx < 16 * 32; idx += 256) {
+        const int co = idx >> 5, e = idx & 31;
+        if (co >= d.Cc || e > 27) continue;
+        const float v = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+        if (e < 27) P[co * 27 + e] = v;
+        else P[d.Cc * 27 + co] = v;
     }
 }
 
@@ -538,59 +560,82 @@ __global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc
 // dw[c][o][a][b] = sum_pix x[pix][c]*gy[o][pix,a,b]; db[o] = sum gy.  Thread (oab, cq) accumulates
 // 4 input channels for one (o,a,b) over the block's pixel slab from LDS tiles; a 5th "channel
 // group" row carries the bias sum.  Slab layout: [ncls*4][16] then [ncls*4] bias partials.
-__global__ __launch_bounds__(512) void outconv_wgrad_kernel(const OutConvBwdDesc d)
+__global__ __launch_bounds__(256) void outconv_wgrad_kernel(const OutConvBwdDesc d)
 {
-    constexpr int PT = 64;                                  // pixels (along j) per tile
-    __shared__ __attribute__((aligned(16))) float xt[PT * OC_CIN];
-    __shared__ float gt[OC_MAX_NCLS * 4 * (PT + 1)];
-    const int tid = threadIdx.x;
-    const int nab = d.ncls * 4;
-    const int oab = tid % 128, cq = tid / 128;              // cq in 0..3 -> channels 4cq..4cq+3
-    const bool active = oab < nab;
-    const long long M = (long long)d.N * d.H * d.W;
-    const long long mbeg = (long long)blockIdx.x * d.split_pixels;
-    long long mend = mbeg + d.split_pixels;
-    if (mend > M) mend = M;
-    const int Ho = 2 * d.H, Wo = 2 * d.W;
-    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-    float bacc = 0.0f;
-    for (long long mb = mbeg; mb < mend; mb += PT) {
-        for (int i = tid; i < PT * OC_CIN / 4; i += 512) {
-            const int p = i / (OC_CIN / 4);
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (mb + p < mend) v = *reinterpret_cast<const f32x4 *>(d.x + (mb + p) * OC_CIN + (i % (OC_CIN / 4)) * 4);
-            *reinterpret_cast<f32x4 *>(&xt[i * 4]) = v;
-        }
-        for (int i = tid; i < nab * PT; i += 512) {
-            const int p = i % PT, q = i / PT;           // q = (o*2 + a)*2 + b
-            const int b = q & 1, a = (q >> 1) & 1, o = q >> 2;
-            const long long m = mb + p;
-            float v = 0.0f;
-            if (m < mend) {
-                const int n = (int)(m / (d.H * d.W));
-                const int rem = (int)(m - (long long)n * d.H * d.W);
-                const int ii = rem / d.W, jj = rem - ii * d.W;
-                v = d.gy[(((long long)n * d.ncls + o) * Ho + 2 * ii + a) * Wo + 2 * jj + b];
-            }
-            gt[q * (PT + 1) + p] = v;
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll 8
-            for (int p = 0; p < PT; ++p) {
-                const float g = gt[oab * (PT + 1) + p];
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(&xt[p * OC_CIN + cq * 4]);
-                acc[0] = fmaf(g, xv[0], acc[0]); acc[1] = fmaf(g, xv[1], acc[1]);
-                acc[2] = fmaf(g, xv[2], acc[2]); acc[3] = fmaf(g, xv[3], acc[3]);
-                bacc += g;
-            }
-        }
-        __syncthreads();
+    // MFMA 16x16x4: row = input channel c, contraction = 4 consecutive input pixels, column = (o,a,b)
+    // in tiles of 16.  Lane (i, g) reads x[pix g][c = i] and, per column tile, the logit gradient
+    // gy[n][o][2y+a][2x+b] of pixel g.  A wave covers a quarter of the block's pixel slab.
+    constexpr int MAXT = OC_MAX_NCLS * 4 / 16;
+    __shared__ float red[4][MAXT * 256 + MAXT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int nab = d.ncls * 4, nt = (nab + 15) / 16;
+    const unsigned HW = (unsigned)d.H * d.W, M = (unsigned)d.N * HW;
+    const unsigned Ho = 2 * d.H, Wo = 2 * d.W;
+    const unsigned wsp = (unsigned)d.split_pixels / 4;                 // multiple of 4 (host)
+    const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
+    unsigned wend = wbeg + wsp;
+    if (wend > M) wend = M;
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x, M * OC_CIN * 4u);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.gy, M * 4u * d.ncls * 4u);
+    // per column tile: this lane's (o, a, b) as an element offset into one image's gy, or padding
+    unsigned coff[MAXT];
+#pragma unroll
+    for (int T = 0; T < MAXT; ++T) {
+        const int oab = 16 * T + i;
+        coff[T] = oab < nab ? ((unsigned)(oab >> 2) * Ho + ((oab >> 1) & 1)) * Wo + (oab & 1) : ERF_OOB;
     }
-    if (active) {
-        float *P = d.partial + (long long)blockIdx.x * (nab * OC_CIN + nab);
-        *reinterpret_cast<f32x4 *>(&P[oab * OC_CIN + cq * 4]) = acc;
-        if (cq == 0) P[nab * OC_CIN + oab] = bacc;
+    f32x4 acc[MAXT];
+    float bsum[MAXT];
+#pragma unroll
+    for (int T = 0; T < MAXT; ++T) { acc[T] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; bsum[T] = 0.0f; }
+
+    struct Frag { float xv, gv[MAXT]; };
+    auto load_group = [&](unsigned m0, Frag &f) {
+        const unsigned m = m0 + g;
+        const bool valid = m < wend;
+        const unsigned mm = valid ? m : 0;
+        const unsigned n = mm / HW, rem = mm - n * HW;
+        const unsigned y = rem / d.W, x = rem - y * d.W;
+        f.xv = buf_load1(r_x, valid ? (mm * OC_CIN + i) * 4u : ERF_OOB);
+        const unsigned base = n * d.ncls * Ho * Wo + 2 * y * Wo + 2 * x;
+#pragma unroll
+        for (int T = 0; T < MAXT; ++T)
+            if (T < nt) f.gv[T] = buf_load1(r_g, (valid && coff[T] != ERF_OOB) ? (base + coff[T]) * 4u : ERF_OOB);
+    };
+    auto mfma_group = [&](const Frag &f) {
+#pragma unroll
+        for (int T = 0; T < MAXT; ++T)
+            if (T < nt) {
+                bsum[T] += f.gv[T];
+                acc[T] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.xv, f.gv[T], acc[T], 0, 0, 0);
+            }
+    };
+    for (unsigned m0 = wbeg; m0 < wend; m0 += 8) {
+        Frag f[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) load_group(m0 + 4 * u, f[u]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mfma_group(f[u]);
+    }
+    // D[row = c = 4g + r][col = oab = 16T + i]; bias sums over the pixel index g
+#pragma unroll
+    for (int T = 0; T < MAXT; ++T) {
+        if (T >= nt) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(16 * T + i) * 16 + 4 * g + r] = acc[T][r];
+        float bs = bsum[T];
+        bs += __shfl_xor(bs, 16);
+        bs += __shfl_xor(bs, 32);
+        if (g == 0) red[wave][MAXT * 256 + 16 * T + i] = bs;
+    }
+    __syncthreads();
+    float *P = d.partial + (long long)blockIdx.x * (nab * OC_CIN + nab);
+    for (int idx = tid; idx < nab * OC_CIN; idx += 256)
+        P[idx] = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+    for (int idx = tid; idx < nab; idx += 256) {
+        const int e = MAXT * 256 + idx;
+        P[nab * OC_CIN + idx] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
     }
 }
 

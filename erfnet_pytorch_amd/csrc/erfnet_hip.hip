@@ -698,15 +698,18 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
     }
     if (Cin == 3) {
         const int nw = Cc * 27;
-        long long nsplit = (Mo + 2047) / 2048;
-        if (nsplit > 1024) nsplit = 1024;
+        long long nsplit = (Mo + 1023) / 1024;
+        if (nsplit > 512) nsplit = 512;
         long long sp = (Mo + nsplit - 1) / nsplit;
-        sp = (sp + 63) / 64 * 64;
+        sp = (sp + 15) / 16 * 16;
         nsplit = (Mo + sp - 1) / sp;
         float *partial = ar.floats((size_t)nsplit * (nw + Cc));
         if (!partial) return fail("DownsamplerBlock backward: workspace too small");
-        FirstDownWgradDesc d = {x, sn, sc, sh, sw, g, partial, N, H, W, Cc, Cout, (int)sp};
-        first_down_wgrad_kernel<<<(unsigned)nsplit, 512, 0, st>>>(d);
+        const long long x_elems = (long long)(N - 1) * sn + 2 * sc + (long long)(H - 1) * sh + (long long)(W - 1) * sw + 1;
+        if (x_elems >= (1LL << 29) || Mo * Cout >= (1LL << 29) || sn < 0 || sc < 0 || sh < 0 || sw < 0)
+            return fail("DownsamplerBlock backward: input too large or negatively strided");
+        FirstDownWgradDesc d = {x, sn, sc, sh, sw, g, partial, N, H, W, Cc, Cout, (int)sp, (unsigned)(x_elems * 4)};
+        first_down_wgrad_kernel<<<(unsigned)nsplit, 256, 0, st>>>(d);
         CHECK_LAUNCH("first_down_wgrad_kernel");
         reduce_flat_kernel<<<(nw + Cc + 31) / 32, 256, 0, st>>>(partial, dw, db, (int)nsplit, nw, Cc);
         CHECK_LAUNCH("reduce_flat_kernel");
@@ -1042,10 +1045,12 @@ int erf_outconv_backward(const float *x, const float *w, const float *gy, float 
     const long long M = (long long)N * H * W;
     const int nab = ncls * 4, slab = nab * OC_CIN + nab;
     long long nsplit = (M + 1023) / 1024;
-    if (nsplit > 1024) nsplit = 1024;
+    if (nsplit > 512) nsplit = 512;
     long long sp = (M + nsplit - 1) / nsplit;
-    sp = (sp + 63) / 64 * 64;
+    sp = (sp + 15) / 16 * 16;
     nsplit = (M + sp - 1) / sp;
+    if (M * OC_CIN >= (1LL << 29) || M * 4 * ncls >= (1LL << 29))
+        return fail("output ConvTranspose2d backward: tensors of 2 GiB or more are not supported");
     float *partial = ar.floats((size_t)nsplit * slab);
     if (!partial) return fail("output ConvTranspose2d backward: workspace too small");
     OutConvBwdDesc d = {x, w, gy, dx, partial, N, H, W, ncls, (int)sp, (flags & ERF_BWD_MASK_DX) ? 1 : 0};
@@ -1053,7 +1058,7 @@ int erf_outconv_backward(const float *x, const float *w, const float *gy, float 
         outconv_dgrad_kernel<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
         CHECK_LAUNCH("outconv_dgrad_kernel");
     }
-    outconv_wgrad_kernel<<<(unsigned)nsplit, 512, 0, st>>>(d);
+    outconv_wgrad_kernel<<<(unsigned)nsplit, 256, 0, st>>>(d);
     CHECK_LAUNCH("outconv_wgrad_kernel");
     outconv_wreduce_kernel<<<(slab + 31) / 32, 256, 0, st>>>(partial, dw, db, (int)nsplit, ncls);
     CHECK_LAUNCH("outconv_wreduce_kernel");
