@@ -57,6 +57,7 @@ _PROTOS = {
     "erf_version": (C.c_int, []),
     "erf_last_error": (C.c_char_p, []),
     "erf_launch_count": (C.c_ulonglong, []),
+    "erf_set_option": (C.c_int, [C.c_int, C.c_int]),
     "erf_workspace_bytes": (C.c_size_t, [ll, C.c_int]),
     "erf_downsampler_forward": (C.c_int, [vp, ll, ll, ll, ll, vp, vp, C.POINTER(BnStruct), vp, vp,
                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
@@ -91,6 +92,7 @@ _PROTOS = {
 }
 
 BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
+OPT_PAIR_FUSION = 1
 
 EXPORTS = tuple(_PROTOS)
 
@@ -130,3 +132,8 @@ def check(rc):
 
 def launch_count():
     return int(lib().erf_launch_count())
+
+
+def set_option(option, value):
+    """Tuning switch of the library (include/erfnet_hip.h); returns the previous value."""
+    return int(lib().erf_set_option(int(option), int(value)))

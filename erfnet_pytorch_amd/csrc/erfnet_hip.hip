@@ -5,6 +5,7 @@
 #include "igemm.h"
 #include "stream16.h"
 #include "sampler16.h"
+#include "pair.h"
 #include "loss_kernels.h"
 
 #include <atomic>
@@ -233,6 +234,107 @@ int launch_igemm(IgemmDesc &d, Arena &ar, hipStream_t st)
     if (plan_igemm(d, ar, pk)) return 1;
     if (launch_pack(&pk, 1, st)) return 1;
     return run_igemm(d, st);
+}
+
+// ------------------------------------------------------------------ fused convolution pairs
+// Two consecutive 1-D convolutions of a non_bottleneck_1d (the first across the lines the second
+// runs along) go into one launch of pair_f32_kernel when the line fits a block tile.
+// ERFNET_NO_PAIR=1 keeps every convolution in a launch of its own (experiments, A/B tests).
+std::atomic<int> g_pair_on{-1};
+bool pair_enabled()
+{
+    int on = g_pair_on.load(std::memory_order_relaxed);
+    if (on < 0) {
+        const char *e = getenv("ERFNET_NO_PAIR");
+        on = (e && atoi(e)) ? 0 : 1;
+        g_pair_on.store(on, std::memory_order_relaxed);
+    }
+    return on != 0;
+}
+
+// Tile variant (block pixels) for a line of L pixels and NC channels, 0 = none.
+int pair_tile(int NC, int L)
+{
+    if (NC == 128) return L <= 64 ? (L > 32 ? 64 : 0) : (L <= 128 ? 128 : 0);
+    if (NC == 64) return L <= 128 ? (L > 64 ? 128 : 0) : (L <= 256 ? 256 : 0);
+    return 0;
+}
+
+// a = first convolution, b = second (b.in is a.out).  Returns the tile variant or 0.
+int pair_variant(const IgemmDesc &a, const IgemmDesc &b)
+{
+    if (!pair_enabled()) return 0;
+    const int NC = a.K;
+    const IgemmDesc *dd[2] = {&a, &b};
+    for (const IgemmDesc *d : dd) {
+        if (d->K != NC || d->Nout != NC || d->in_C != NC || d->out_C != NC || d->in_coff || d->out_coff) return 0;
+        if (d->ss != 1 || d->os != 1 || d->ngroups != 1 || d->gtap0[0] != 0 || d->gntaps[0] != 3) return 0;
+        if (d->goa[0] || d->gob[0] || d->epi.nscale) return 0;
+        if (d->N != a.N || d->GH != a.GH || d->GW != a.GW || d->in_H != a.GH || d->in_W != a.GW ||
+            d->out_H != a.GH || d->out_W != a.GW) return 0;
+        if (!aligned16(d->in) || !aligned16(d->out)) return 0;
+        const long long P = (long long)d->N * d->GH * d->GW;
+        if (P * NC >= (1LL << 29)) return 0;
+        if (d->epi.res && P * d->epi.res_C >= (1LL << 29)) return 0;
+        if (d->epi.mask && P * d->epi.mask_C >= (1LL << 29)) return 0;
+    }
+    if (b.in != a.out) return 0;
+    bool a_w = true, a_h = true, b_w = true, b_h = true;
+    for (int t = 0; t < 3; ++t) {
+        a_w = a_w && a.tdh[t] == 0; a_h = a_h && a.tdw[t] == 0;
+        b_w = b_w && b.tdh[t] == 0; b_h = b_h && b.tdw[t] == 0;
+    }
+    if (a_w && b_h) return pair_tile(NC, a.GH);        // lines = image columns
+    if (a_h && b_w) return pair_tile(NC, a.GW);        // lines = image rows
+    return 0;
+}
+
+// Reserve and describe the packed weights (16 channels per K-step) and fill the kernel descriptor.
+// keep_mid = false drops the store of the intermediate tensor.
+int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, PackDesc pk[2], PairDesc &pd)
+{
+    const int NC = a.K;
+    const IgemmDesc *dd[2] = {&a, &b};
+    const float *wp[2];
+    for (int i = 0; i < 2; ++i) {
+        const size_t n = (size_t)3 * NC * NC;
+        float *p = ar.floats(n);
+        if (!p) return fail("conv pair: workspace too small for the packed weights (%zu floats)", n);
+        wp[i] = p;
+        PackDesc &k = pk[i];
+        memset(&k, 0, sizeof(k));
+        k.w = dd[i]->w; k.wp = p; k.ntaps = 3; k.K = NC; k.Nout = NC; k.Npad = NC;
+        k.wsk = dd[i]->wsk; k.wsn = dd[i]->wsn; k.kc = 16;
+        for (int t = 0; t < 3; ++t) k.woff[t] = dd[i]->woff[t];
+    }
+    memset(&pd, 0, sizeof(pd));
+    pd.in = a.in; pd.wp1 = wp[0]; pd.wp2 = wp[1];
+    pd.mid = keep_mid ? a.out : nullptr;
+    pd.out = b.out;
+    pd.epi1 = a.epi; pd.epi2 = b.epi;
+    pd.N = a.N; pd.img_pixels = a.GH * a.GW;
+    const bool columns = a.tdh[0] == 0 && a.tdh[2] == 0;
+    if (columns) {
+        pd.lines_per_img = a.GW; pd.L = a.GH; pd.pstride = a.GW; pd.qstride = 1;
+        for (int t = 0; t < 3; ++t) { pd.s1[t] = a.tdw[t]; pd.s2[t] = b.tdh[t]; }
+    } else {
+        pd.lines_per_img = a.GH; pd.L = a.GW; pd.pstride = 1; pd.qstride = a.GW;
+        for (int t = 0; t < 3; ++t) { pd.s1[t] = a.tdh[t]; pd.s2[t] = b.tdw[t]; }
+    }
+    pd.nlines = a.N * pd.lines_per_img;
+    return 0;
+}
+
+int run_pair(const PairDesc &pd, int NC, int tile, hipStream_t st)
+{
+    if (pd.nlines == 0) return 0;
+    if (NC == 128 && tile == 64) pair_f32_kernel<64, 128><<<pd.nlines, 256, 0, st>>>(pd);
+    else if (NC == 128 && tile == 128) pair_f32_kernel<128, 128><<<pd.nlines, 256, 0, st>>>(pd);
+    else if (NC == 64 && tile == 128) pair_f32_kernel<128, 64><<<pd.nlines, 256, 0, st>>>(pd);
+    else if (NC == 64 && tile == 256) pair_f32_kernel<256, 64><<<pd.nlines, 256, 0, st>>>(pd);
+    else return fail("conv pair: no kernel for %d channels, tile %d", NC, tile);
+    CHECK_LAUNCH("pair_f32_kernel");
+    return 0;
 }
 
 // Weight gradients of up to four convolutions of identical geometry (the four 1-D convolutions of
@@ -603,6 +705,16 @@ ParityTaps parity_taps()
 extern "C" {
 
 int erf_version(void) { return 100; }
+
+int erf_set_option(int option, int value)
+{
+    if (option == ERF_OPT_PAIR_FUSION) {
+        const int prev = pair_enabled() ? 1 : 0;
+        g_pair_on.store(value ? 1 : 0, std::memory_order_relaxed);
+        return prev;
+    }
+    return -1;
+}
 const char *erf_last_error(void) { return g_err; }
 unsigned long long erf_launch_count(void) { return g_launches.load(); }
 
@@ -812,21 +924,33 @@ int erf_nb1d_forward(const float *x, const float *const w[4], const float *const
         d[3].epi.res = x; d[3].epi.res_C = C; d[3].epi.res_coff = 0;
         d[3].epi.relu = 1;
     }
-    for (int i = 0; i < 4; ++i)
-        if (plan_igemm(d[i], ar, pk[i])) return 1;
+    // conv1x3_1 -> conv3x1_2 as one launch over image columns when nothing sits between them
+    const int pair12 = tp1 ? 0 : pair_variant(d[1], d[2]);
+    PairDesc pd12;
+    if (pair12) {
+        if (plan_igemm(d[0], ar, pk[0]) || plan_igemm(d[3], ar, pk[3])) return 1;
+        if (plan_pair(d[1], d[2], save != nullptr, ar, pk + 1, pd12)) return 1;
+    } else {
+        for (int i = 0; i < 4; ++i)
+            if (plan_igemm(d[i], ar, pk[i])) return 1;
+    }
     if (launch_pack(pk, 4, st)) return 1;      // one launch repacks all four weight tensors
 
     if (run_igemm(d[0], st)) return 1;
-    if (run_igemm(d[1], st)) return 1;
-    if (tp1) {
-        if (m1 == 2) { if (bn_train_stats(bn1, p2, M, C, ar, st)) return 1; }
-        else if (bn_eval_prepare(bn1, C, st)) return 1;
-        Epilogue e = kNoEpi;
-        e.bn = m1 == 2 ? bn_saved_affine(bn1) : bn_eval_affine(bn1);
-        e.relu = 1;
-        if (launch_elt(p2, t2, e, M, C, H * W, st)) return 1;
+    if (pair12) {
+        if (run_pair(pd12, C, pair12, st)) return 1;
+    } else {
+        if (run_igemm(d[1], st)) return 1;
+        if (tp1) {
+            if (m1 == 2) { if (bn_train_stats(bn1, p2, M, C, ar, st)) return 1; }
+            else if (bn_eval_prepare(bn1, C, st)) return 1;
+            Epilogue e = kNoEpi;
+            e.bn = m1 == 2 ? bn_saved_affine(bn1) : bn_eval_affine(bn1);
+            e.relu = 1;
+            if (launch_elt(p2, t2, e, M, C, H * W, st)) return 1;
+        }
+        if (run_igemm(d[2], st)) return 1;
     }
-    if (run_igemm(d[2], st)) return 1;
     if (run_igemm(d[3], st)) return 1;
     if (tp2) {
         if (m2 == 2) { if (bn_train_stats(bn2, p4, M, C, ar, st)) return 1; }
@@ -881,8 +1005,19 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     conv1d_desc(d[0], g1, w[0], dx, N, C, H, W, 0, 1, true);        // + g4 (residual path)
     d[0].epi.res = g4; d[0].epi.res_C = C;
     if (flags & ERF_BWD_MASK_DX) { d[0].epi.mask = x; d[0].epi.mask_C = C; }
-    for (int i = 0; i < 4; ++i)
-        if (plan_igemm(d[i], ar, pk[i])) return 1;
+    // each half of the chain is "along W, then along H": one launch over image columns
+    const int pair32 = pair_variant(d[3], d[2]), pair10 = pair_variant(d[1], d[0]);
+    PairDesc pd32, pd10;
+    if (pair32) {
+        PackDesc two[2];
+        if (plan_pair(d[3], d[2], true, ar, two, pd32)) return 1;
+        pk[3] = two[0]; pk[2] = two[1];
+    } else if (plan_igemm(d[3], ar, pk[3]) || plan_igemm(d[2], ar, pk[2])) return 1;
+    if (pair10) {
+        PackDesc two[2];
+        if (plan_pair(d[1], d[0], true, ar, two, pd10)) return 1;
+        pk[1] = two[0]; pk[0] = two[1];
+    } else if (plan_igemm(d[1], ar, pk[1]) || plan_igemm(d[0], ar, pk[0])) return 1;
     if (launch_pack(pk, 4, st)) return 1;
     // BatchNorm scratch first; the slabs of the four weight gradients follow it
     const size_t bn_bytes = 2 * (sizeof(double) * 2 * (size_t)C + 256);
@@ -900,14 +1035,16 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
         if (launch_elt(g4, gsbuf, e, M, C, H * W, st)) return 1;
     }
     // data-gradient chain: gs -> gb -> ga [-> gn] -> g1 -> dx = dgrad + g4
-    if (run_igemm(d[3], st)) return 1;
-    if (run_igemm(d[2], st)) return 1;
+    if (pair32) {
+        if (run_pair(pd32, C, pair32, st)) return 1;
+    } else if (run_igemm(d[3], st) || run_igemm(d[2], st)) return 1;
     if (m1) {
         if (bn_backward(bn1, p2, ga, nullptr, nullptr, gnbuf, dgamma ? dgamma[0] : nullptr,
                         dbeta ? dbeta[0] : nullptr, M, C, H * W, bn_ar, st)) return 1;
     }
-    if (run_igemm(d[1], st)) return 1;
-    if (run_igemm(d[0], st)) return 1;
+    if (pair10) {
+        if (run_pair(pd10, C, pair10, st)) return 1;
+    } else if (run_igemm(d[1], st) || run_igemm(d[0], st)) return 1;
     // the four weight gradients in one launch: (x, g1), (t1, gn), (t2, gb), (t3, gs)
     WgradDesc wd[4];
     wgrad1d_desc(wd[0], x, g1, N, C, H, W, 0, 1);

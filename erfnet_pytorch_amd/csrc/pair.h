@@ -1,0 +1,250 @@
+// Two chained 1-D convolutions of a non_bottleneck_1d in one launch (gfx950, fp32 MFMA 32x32x2).
+//
+//   mid = epi1( conv_a(in) )        conv_a runs ACROSS lines  (tap shift s1[t] lines)
+//   out = epi2( conv_b(mid) )       conv_b runs ALONG a line  (tap shift s2[t] pixels of the line)
+//
+// A block owns one whole line of the image (an image column of H pixels for a "1x3 then 3x1" pair:
+// conv_a reaches into the neighbouring columns of `in`, conv_b stays inside the column), so the
+// second convolution needs no halo: its A operand is the block's own `mid` tile, kept in LDS.
+// `mid` is also written to memory when the caller needs it (training saves it for backward).
+// Compared with two igemm launches this removes one launch ramp, the re-read of `mid`, and lets the
+// first epilogue of one block overlap the MFMAs of its neighbours on the CU.
+//
+// Both convolutions are NC -> NC channels (NC = 64 or 128), 3 taps, dense NHWC tensors.  The
+// contraction visits taps, then channels in ascending groups of 8 — the order igemm_f32_kernel
+// uses — so the results are bit-identical to the two-launch path.
+#pragma once
+#include "common.h"
+
+struct PairDesc {
+    const float *in;
+    const float *wp1, *wp2;     // packed weights [tap][NC/16][NC][16]
+    float *mid;                 // may be null (inference: the intermediate never leaves the CU)
+    float *out;
+    Epilogue epi1, epi2;        // nscale is not supported (must be null)
+    int N, nlines, lines_per_img, img_pixels;
+    int L;                      // pixels per line (<= BM)
+    int pstride;                // pixel-index distance between neighbours on a line
+    int qstride;                // pixel-index distance between the bases of neighbouring lines
+    int s1[3], s2[3];
+};
+
+// 16-byte chunk swizzle of the mid tile (row pitch = NC floats, a multiple of the 64 banks): any 16
+// consecutive rows map to 16 different chunk slots (conflict-free ds_read_b128 with lanes = rows,
+// also for tap-shifted rows), and rows r, r+4 land in different bank halves (the two lane halves of
+// an accumulator store).
+__device__ __forceinline__ int mid_swz(int row, int chunk)
+{
+    return chunk ^ ((row & 7) | ((((row >> 3) ^ (row >> 2)) & 1) << 3));
+}
+
+template <int BM, int NC>
+__global__ __launch_bounds__(256, (BM * NC <= 8192 ? 3 : 2)) void pair_f32_kernel(const PairDesc d)
+{
+    constexpr int KC = 16, CPR = KC / 4, BPITCH = KC + 4, NT = 256, KCH = NC / KC;
+    constexpr int GN = NC / 32, GM = 4 / GN, WM = BM / (32 * GM);
+    static_assert(GM >= 1 && WM >= 1 && GM * WM * 32 == BM, "tile shape");
+    constexpr int A_SLOTS = BM * CPR, B_SLOTS = NC * CPR;
+    constexpr int A_PASSES = (A_SLOTS + NT - 1) / NT, B_PASSES = B_SLOTS / NT;
+    static_assert(B_SLOTS % NT == 0 && A_SLOTS % NT == 0, "whole passes");
+    constexpr int NSTEPS = 3 * KCH;
+    // mid tile [BM][NC] + one row of zeros (taps of conv_b beyond the line read it); while conv_a
+    // runs, its first 2*BM*KC floats are the double-buffered A staging area
+    __shared__ __attribute__((aligned(16))) float Ts[(BM + 1) * NC];
+    __shared__ __attribute__((aligned(16))) float Bs[2][NC * BPITCH];
+    static_assert(2 * BM * KC <= BM * NC, "A staging fits inside the mid tile");
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / GN, wn = wave % GN;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const unsigned line = xcd_tile(blockIdx.x, gridDim.x);
+    const int n = (int)(line / (unsigned)d.lines_per_img);
+    const int q = (int)(line - (unsigned)n * d.lines_per_img);
+    const unsigned base = (unsigned)n * d.img_pixels + (unsigned)q * d.qstride;
+    const int L = d.L;
+    const int s1a = d.s1[0], s1b = d.s1[1], s1c = d.s1[2], s2a = d.s2[0], s2b = d.s2[1], s2c = d.s2[2];
+
+    for (int i = tid; i < NC; i += NT) Ts[BM * NC + i] = 0.0f;
+
+    // per-column constants of both epilogues
+    const int col = wn * 32 + l31;
+    float sc1, sh1, sc2, sh2;
+    epi_channel_affine(d.epi1, col, sc1, sh1);
+    epi_channel_affine(d.epi2, col, sc2, sh2);
+
+    f32x16 acc[WM];
+    auto clear_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    };
+    clear_acc();
+
+    const unsigned P = (unsigned)d.N * d.img_pixels;
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, P * NC * 4u);
+
+    struct Stage {
+        f32x4 a[A_PASSES], b[B_PASSES];
+    };
+    // ------------------------------------------------------------------ conv_a: A and B from memory
+    auto load1 = [&](int s, Stage &R) {
+        const int t = s / KCH, kc = s % KCH;
+        const int sh = t == 0 ? s1a : (t == 1 ? s1b : s1c);
+        const unsigned tapbad = (unsigned)(q + sh) < (unsigned)d.lines_per_img ? 0u : ERF_OOB;
+        const unsigned tbase = base + (unsigned)(sh * d.qstride);
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int slot = tid + i * NT;
+            const int r = slot / CPR, ac = slot % CPR;
+            unsigned off = ((tbase + (unsigned)(r * d.pstride)) * NC + kc * KC + ac * 4) * 4u;
+            off |= tapbad | ((unsigned)((L - 1 - r) >> 31) & ERF_OOB);
+            R.a[i] = buf_load4(r_in, off);
+        }
+        const float *wt = d.wp1 + (long long)(t * KCH + kc) * NC * KC;
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i)
+            R.b[i] = *reinterpret_cast<const f32x4 *>(wt + (tid + i * NT) * 4);
+    };
+    auto store_b = [&](int buf, const f32x4 *b) {
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int slot = tid + i * NT;
+            *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = b[i];
+        }
+    };
+    auto store1 = [&](int buf, const Stage &R) {
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) {
+            const int slot = tid + i * NT;
+            const int r = slot / CPR, ac = slot % CPR;
+            *reinterpret_cast<f32x4 *>(&Ts[buf * BM * KC + r * KC + ((ac ^ ((r >> 2) & 3)) << 2)]) = R.a[i];
+        }
+        store_b(buf, R.b);
+    };
+    auto step1 = [&](int s, Stage &R) {
+        const int buf = s & 1;
+        if (s + 1 < NSTEPS) store1(buf ^ 1, R);
+        if (s + 2 < NSTEPS) load1(s + 2, R);
+        const float *Ab = Ts + buf * BM * KC, *Bb = Bs[buf];
+#pragma unroll
+        for (int qq = 0; qq < KC / 8; ++qq) {
+            f32x4 af[WM], bf;
+#pragma unroll
+            for (int a = 0; a < WM; ++a) {
+                const int row = (wm * WM + a) * 32 + l31;
+                af[a] = *reinterpret_cast<const f32x4 *>(&Ab[row * KC + (((2 * qq + h) ^ ((row >> 2) & 3)) << 2)]);
+            }
+            bf = *reinterpret_cast<const f32x4 *>(&Bb[col * BPITCH + qq * 8 + h * 4]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[m], acc[a], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+
+    Stage st0;
+    {
+        Stage st1;
+        load1(0, st0);
+        load1(1, st1);
+        store1(0, st0);
+        st0 = st1;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int s = 0; s < NSTEPS; ++s) step1(s, st0);
+
+    // ------------------------------------------------------------------ epilogues
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    auto epilogue = [&](const Epilogue &e, float sc, float sh, float *dst, bool to_lds) {
+        const __amdgpu_buffer_rsrc_t r_out = make_rsrc(dst, P * NC * 4u);
+        const __amdgpu_buffer_rsrc_t r_res = make_rsrc(e.res, P * e.res_C * 4u);
+        const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(e.mask, P * e.mask_C * 4u);
+        const bool has_mask = e.mask != nullptr, relu = e.relu != 0;
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                unsigned opx[8], rbad[8];
+                int rw[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = hf * 8 + k;
+                    rw[k] = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    opx[k] = base + (unsigned)(rw[k] * d.pstride);
+                    rbad[k] = (unsigned)((L - 1 - rw[k]) >> 31) & ERF_OOB;
+                }
+                float rres[8], rmask[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    rres[k] = buf_load1(r_res, ((opx[k] * e.res_C + e.res_coff + col) * 4u) | rbad[k]);
+                    rmask[k] = buf_load1(r_mask, ((opx[k] * e.mask_C + e.mask_coff + col) * 4u) | rbad[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float v = acc[a][hf * 8 + k] * sc + sh;
+                    v += rres[k];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    v = (!has_mask || rmask[k] > 0.0f) ? v : 0.0f;
+                    buf_store1(r_out, ((opx[k] * NC + col) * 4u) | rbad[k], v);
+                    if (to_lds) Ts[rw[k] * NC + (mid_swz(rw[k], col >> 2) << 2) + (col & 3)] = v;
+                }
+            }
+        }
+    };
+
+    // conv_b's first two weight tiles travel while the first epilogue runs
+    f32x4 wb0[B_PASSES], wb1[B_PASSES];
+    auto load_w2 = [&](int s, f32x4 *b) {
+        const float *wt = d.wp2 + (long long)s * NC * KC;
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) b[i] = *reinterpret_cast<const f32x4 *>(wt + (tid + i * NT) * 4);
+    };
+    load_w2(0, wb0);
+    load_w2(1, wb1);
+    epilogue(d.epi1, sc1, sh1, d.mid, true);
+    store_b(0, wb0);
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) wb0[i] = wb1[i];
+    clear_acc();
+    __syncthreads();
+
+    // ------------------------------------------------------------------ conv_b: A = mid tile in LDS
+#pragma unroll 2
+    for (int s = 0; s < NSTEPS; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < NSTEPS) store_b(buf ^ 1, wb0);
+        if (s + 2 < NSTEPS) load_w2(s + 2, wb0);
+        const int t = s / KCH, kc = s % KCH;
+        const int sh = t == 0 ? s2a : (t == 1 ? s2b : s2c);
+        const float *Bb = Bs[buf];
+        const float *arow[WM];
+        int asw[WM];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+            const int rr = (wm * WM + a) * 32 + l31 + sh;
+            const int rz = (unsigned)rr < (unsigned)L ? rr : BM;       // beyond the line: the zero row
+            arow[a] = Ts + rz * NC;
+            asw[a] = (rz & 7) | ((((rz >> 3) ^ (rz >> 2)) & 1) << 3);
+        }
+#pragma unroll
+        for (int qq = 0; qq < KC / 8; ++qq) {
+            f32x4 af[WM], bf;
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+                af[a] = *reinterpret_cast<const f32x4 *>(arow[a] + (((kc * CPR + 2 * qq + h) ^ asw[a]) << 2));
+            bf = *reinterpret_cast<const f32x4 *>(&Bb[col * BPITCH + qq * 8 + h * 4]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[m], acc[a], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    epilogue(d.epi2, sc2, sh2, d.out, false);
+}

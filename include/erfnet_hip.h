@@ -50,6 +50,13 @@ const char *erf_last_error(void);
  * prove the HIP path, not a fallback, produced a result). */
 unsigned long long erf_launch_count(void);
 
+/* Tuning switches (no counterpart in the reference).  erf_set_option returns the previous value,
+ * or -1 for an unknown option.  ERF_OPT_PAIR_FUSION (default 1; environment ERFNET_NO_PAIR=1 turns
+ * it off): consecutive 1-D convolutions of a non_bottleneck_1d run as one launch where the image
+ * geometry allows; results are bit-identical either way. */
+#define ERF_OPT_PAIR_FUSION 1
+int erf_set_option(int option, int value);
+
 /* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block
  * receives is first masked by (its output > 0).  A block whose input x is itself such a ReLU
  * output may apply the producer's mask to the dx it hands back (ERF_BWD_MASK_DX: dx *= (x > 0),
