@@ -447,6 +447,58 @@ def test_graphed_forward_replays_the_eager_result():
         g(x1[:, :, :32])
 
 
+@pytest.mark.parametrize("C_,d,N,H,W", [(128, 2, 2, 40, 24), (128, 16, 1, 64, 20), (64, 1, 2, 72, 20),
+                                        (64, 2, 1, 128, 12)])
+@pytest.mark.parametrize("bn_mode", [0, 1, 2])
+def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
+    """Two chained 1-D convolutions in one launch (pair_f32_kernel, image columns as block tiles)
+    must reproduce the one-launch-per-convolution path bit for bit: inference output, training
+    output, input gradient and every parameter gradient, with and without BatchNorm."""
+    from erfnet_pytorch_amd import functional as hipf, _lib
+    g = torch.Generator(device="cpu").manual_seed(C_ + d + H)
+    x = torch.randn(N, C_, H, W, generator=g).clamp_(min=0).to(DEV).contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(C_, C_, *k, generator=g) * 0.05).to(DEV).requires_grad_(True) for k in ((3, 1), (1, 3), (3, 1), (1, 3))]
+    bs = [(torch.randn(C_, generator=g) * 0.1).to(DEV).requires_grad_(True) for _ in range(4)]
+    gy = torch.randn(N, C_, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    bnp = [[(torch.rand(C_, generator=g) + 0.5).to(DEV).requires_grad_(True),
+            (torch.randn(C_, generator=g) * 0.1).to(DEV).requires_grad_(True)] for _ in range(2)]
+    params = ws + bs + (bnp[0] + bnp[1] if bn_mode else [])
+
+    def run(train):
+        stats = [(torch.randn(C_, generator=torch.Generator().manual_seed(5 + i)) * 0.1).to(DEV) for i in range(2)]
+        var = [(torch.rand(C_, generator=torch.Generator().manual_seed(9 + i)) + 0.5).to(DEV) for i in range(2)]
+        kw = {}
+        if bn_mode:
+            kw = dict(bn1=(bnp[0][0], bnp[0][1], stats[0], var[0]), bn2=(bnp[1][0], bnp[1][1], stats[1], var[1]),
+                      bn_mode=bn_mode)
+        if not train:
+            with torch.no_grad():
+                return [hipf.nb1d(x, ws, bs, d, **kw)]
+        for q in params:
+            q.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = hipf.nb1d(xx, ws, bs, d, **kw)
+        y.backward(gy)
+        return [y.detach(), xx.grad] + [q.grad.clone() for q in params] + (stats + var if bn_mode else [])
+
+    res = {}
+    prev = _lib.set_option(_lib.OPT_PAIR_FUSION, 1)
+    try:
+        for on in (0, 1):
+            _lib.set_option(_lib.OPT_PAIR_FUSION, on)
+            n0 = launches(); a = run(False); n1 = launches(); b = run(True); n2 = launches()
+            res[on] = (a + b, n1 - n0, n2 - n1)
+    finally:
+        _lib.set_option(_lib.OPT_PAIR_FUSION, prev)
+    # without BatchNorm the forward pair and both backward pairs fuse; a BatchNorm whose output is
+    # kept for backward sits between the two convolutions of the forward pair, never between those
+    # of the backward pairs
+    assert res[1][1] == res[0][1] - (0 if bn_mode else 1)
+    assert res[1][2] == res[0][2] - (2 if bn_mode else 3)
+    for i, (u, v) in enumerate(zip(res[0][0], res[1][0])):
+        assert torch.equal(u, v), f"tensor {i}"
+
+
 # ------------------------------------------------------------- full benchmark size: properties
 def _torch_nb1d(x, ws, bs, d):
     import torch.nn.functional as F
