@@ -307,6 +307,8 @@ int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, 
         k.wsk = dd[i]->wsk; k.wsn = dd[i]->wsn; k.kc = 16;
         for (int t = 0; t < 3; ++t) k.woff[t] = dd[i]->woff[t];
     }
+    if (b.out == a.in || (keep_mid && a.out == a.in))
+        return fail("conv pair: the output must not alias the input (other blocks still read it)");
     memset(&pd, 0, sizeof(pd));
     pd.in = a.in; pd.wp1 = wp[0]; pd.wp2 = wp[1];
     pd.mid = keep_mid ? a.out : nullptr;
@@ -927,6 +929,12 @@ int erf_nb1d_forward(const float *x, const float *const w[4], const float *const
     // conv1x3_1 -> conv3x1_2 as one launch over image columns when nothing sits between them
     const int pair12 = tp1 ? 0 : pair_variant(d[1], d[2]);
     PairDesc pd12;
+    if (pair12 && !save) {
+        // the pair reads neighbouring columns of t1 while other blocks write their columns of t3:
+        // the two must not share a buffer; the intermediate's buffer is free (it stays in LDS)
+        d[2].out = p2;
+        d[3].in = p2;
+    }
     if (pair12) {
         if (plan_igemm(d[0], ar, pk[0]) || plan_igemm(d[3], ar, pk[3])) return 1;
         if (plan_pair(d[1], d[2], save != nullptr, ar, pk + 1, pd12)) return 1;

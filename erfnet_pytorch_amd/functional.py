@@ -80,7 +80,7 @@ class _Bn:
         self.save_mean = self.save_invstd = None
         if saved is not None:
             self.save_mean, self.save_invstd = saved
-        elif self.mode and need_save:
+        elif self.mode == 2 or (self.mode and need_save):     # batch statistics always land here
             c = gamma.numel()
             self.save_mean = torch.empty(c, dtype=torch.float32, device=gamma.device)
             self.save_invstd = torch.empty(c, dtype=torch.float32, device=gamma.device)
@@ -103,10 +103,14 @@ def _arr(ts):
 # no other consumer contributed to it.  Masking is idempotent, so every other case (no token,
 # several consumers, a copy in between) simply takes the ordinary path.
 class _ReluToken:
-    __slots__ = ("dx",)
+    __slots__ = ("dx", "grad_on")
 
     def __init__(self):
         self.dx = None
+        # Function.forward always runs with grad mode off and ctx.needs_input_grad ignores
+        # torch.no_grad(), so the wrapper (which creates the token) records the caller's mode:
+        # inference under no_grad keeps no activations and folds eval-mode BatchNorm
+        self.grad_on = torch.is_grad_enabled()
 
 
 def _input_token(x):
@@ -185,7 +189,7 @@ class _Downsampler(torch.autograd.Function):
             x = _nhwc(x)     # a 3-channel image is read through its strides unless dx is wanted
         elif x.dtype != torch.float32:
             raise TypeError("erfnet_hip kernels compute in fp32")
-        need = any(ctx.needs_input_grad)
+        need = out_token.grad_on and any(ctx.needs_input_grad)
         bn = _Bn(mode, gamma, beta, rm, rv, momentum, eps, need)
         wq, bq = _param(w), _param(b)
         if h % 2 or wd % 2:
@@ -250,7 +254,7 @@ class _Nb1d(torch.autograd.Function):
         ctx.out_token = out_token
         x = _nhwc(x)
         n, c, h, wd = x.shape
-        need = any(ctx.needs_input_grad)
+        need = out_token.grad_on and any(ctx.needs_input_grad)
         ws_ = [_param(t) for t in (w0, w1, w2, w3)]
         bs_ = [_param(t) for t in (b0, b1, b2, b3)]
         bn1 = _Bn(mode, g1, be1, rm1, rv1, momentum, eps, need)
@@ -330,7 +334,7 @@ class _Upsampler(torch.autograd.Function):
         x = _nhwc(x)
         n, cin, h, wd = x.shape
         cout = w.shape[1]
-        need = any(ctx.needs_input_grad)
+        need = out_token.grad_on and any(ctx.needs_input_grad)
         bn = _Bn(mode, gamma, beta, rm, rv, momentum, eps, need)
         wq, bq = _param(w), _param(b)
         y = _empty_nhwc(n, cout, 2 * h, 2 * wd, x)

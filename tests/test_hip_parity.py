@@ -490,10 +490,11 @@ def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
             res[on] = (a + b, n1 - n0, n2 - n1)
     finally:
         _lib.set_option(_lib.OPT_PAIR_FUSION, prev)
-    # without BatchNorm the forward pair and both backward pairs fuse; a BatchNorm whose output is
-    # kept for backward sits between the two convolutions of the forward pair, never between those
+    # without BatchNorm the forward pair and both backward pairs fuse; inference folds eval-mode
+    # BatchNorm into the epilogue (pair possible); batch statistics, or a BatchNorm whose input is
+    # kept for backward, sit between the two convolutions of the forward pair, never between those
     # of the backward pairs
-    assert res[1][1] == res[0][1] - (0 if bn_mode else 1)
+    assert res[1][1] == res[0][1] - (0 if bn_mode == 2 else 1)
     assert res[1][2] == res[0][2] - (2 if bn_mode else 3)
     for i, (u, v) in enumerate(zip(res[0][0], res[1][0])):
         assert torch.equal(u, v), f"tensor {i}"
