@@ -33,6 +33,12 @@ class BnStruct(C.Structure):
                 ("momentum", C.c_float), ("eps", C.c_float)]
 
 
+class Nb1dBlockStruct(C.Structure):
+    """Mirror of ``erf_nb1d_block_t``."""
+    _fields_ = [("w", vp * 4), ("b", vp * 4), ("bn1", C.POINTER(BnStruct)), ("bn2", C.POINTER(BnStruct)),
+                ("drop_scale", vp), ("dil", C.c_int), ("y", vp), ("save", C.POINTER(vp))]
+
+
 def sources():
     return [os.path.join(_SRC, f) for f in sorted(os.listdir(_SRC))] + \
         [os.path.join(os.path.dirname(_HERE), "include", "erfnet_hip.h")]
@@ -68,6 +74,8 @@ _PROTOS = {
     "erf_nb1d_forward": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(BnStruct),
                                    C.POINTER(BnStruct), vp, C.c_int, vp, C.POINTER(vp), C.c_int,
                                    C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "erf_nb1d_chain_forward": (C.c_int, [vp, C.POINTER(Nb1dBlockStruct), C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, vp, C.c_size_t, vp]),
     "erf_nb1d_backward": (C.c_int, [vp, C.POINTER(vp), C.POINTER(BnStruct), C.POINTER(BnStruct), vp,
                                     C.c_int, vp, C.POINTER(vp), vp, vp, C.POINTER(vp),
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,

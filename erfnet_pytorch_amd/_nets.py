@@ -10,7 +10,8 @@ import torch.nn as nn
 
 from . import functional as hipf
 from .erfnet_blocks import (DecoderBlock, DecoderBlockSmall, DownsamplerBlock, LadderBlock,
-                            OutputConvTranspose, SoftMaxConv, UpsamplerBlock, non_bottleneck_1d)
+                            OutputConvTranspose, SoftMaxConv, UpsamplerBlock, non_bottleneck_1d,
+                            run_layers)
 
 DILATIONS = (2, 4, 8, 16)
 
@@ -57,15 +58,9 @@ class TrainEncoder(nn.Module):
     def forward(self, input):
         out1 = self.initial_block(input)
         if not self.ladder:
-            for layer in self.layers:
-                out1 = layer(out1)
-            return out1
-        out2 = out1
-        for layer in self.block1:
-            out2 = layer(out2)
-        out3 = out2
-        for layer in self.block2:
-            out3 = layer(out3)
+            return run_layers(self.layers, out1)
+        out2 = run_layers(self.block1, out1)
+        out3 = run_layers(self.block2, out2)
         return out1, out2, out3
 
 

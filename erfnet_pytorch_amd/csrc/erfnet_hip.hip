@@ -878,99 +878,171 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
 }
 
 // ================================================================================ non_bottleneck_1d
+// Forward of a chain of non_bottleneck_1d blocks (y_0 = block_0(x), y_i = block_i(y_{i-1})).
+// Launch plan per block: conv3x1_1 | conv1x3_1 + conv3x1_2 (pair over image columns) | conv1x3_2;
+// inside a chain a block's conv1x3_2 and the next block's conv3x1_1 form one more such pair
+// ("along W, then along H"), whose intermediate is the block output.
+namespace {
+struct Nb1dPlan {
+    IgemmDesc d[4];
+    int m1, m2;
+    bool tp1, tp2;
+    float *p2, *t2, *p4;
+    int pair12, pair_next;      // tile variants, 0 = separate launches
+    PairDesc pd12, pdn;
+};
+constexpr int kMaxChain = 8;
+
+int nb1d_chain_segment(const float *x, const erf_nb1d_block_t *blk, int nb, int N, int C, int H, int W,
+                       Arena &ar, hipStream_t st)
+{
+    const long long M = (long long)N * H * W;
+    const size_t nel = (size_t)M * C;
+    static thread_local Nb1dPlan plan[kMaxChain];
+    PackDesc pk[kMaxChain * 4];
+    float *wa = nullptr, *wc = nullptr;          // scratch tensors of blocks that keep nothing
+    for (int i = 0; i < nb; ++i) {
+        const erf_nb1d_block_t &B = blk[i];
+        Nb1dPlan &P = plan[i];
+        if (B.dil < 1) return fail("non_bottleneck_1d: dilation must be >= 1");
+        const float *xin = i ? blk[i - 1].y : x;
+        P.m1 = bn_mode(B.bn1); P.m2 = bn_mode(B.bn2);
+        // Two-pass BatchNorm (conv -> pre, [statistics,] normalise) in train mode and whenever the
+        // activations are saved for backward; eval-mode inference folds BN into the conv epilogue.
+        P.tp1 = P.m1 == 2 || (P.m1 == 1 && B.save);
+        P.tp2 = P.m2 == 2 || (P.m2 == 1 && B.save);
+        float *t1, *t3;
+        if (B.save) {
+            t1 = B.save[0]; P.p2 = B.save[1]; P.t2 = B.save[2]; t3 = B.save[3]; P.p4 = B.save[4];
+            if ((P.m1 && !P.p2) || (P.m2 && !P.p4)) return fail("non_bottleneck_1d: BatchNorm needs the pre2/pre4 buffers");
+        } else {
+            if (!wa) { wa = ar.floats(nel); wc = ar.floats(nel); }
+            if (!wa || !wc) return fail("non_bottleneck_1d: workspace too small");
+            t1 = wa; P.p2 = wc; P.t2 = wc; t3 = wa; P.p4 = wc;
+        }
+        IgemmDesc *d = P.d;
+        // conv3x1_1 + ReLU
+        conv1d_desc(d[0], xin, B.w[0], t1, N, C, H, W, 0, 1, false);
+        d[0].epi.bias = B.b[0]; d[0].epi.relu = 1;
+        // conv1x3_1 [+ BN1] + ReLU
+        conv1d_desc(d[1], t1, B.w[1], P.tp1 ? P.p2 : P.t2, N, C, H, W, 1, 1, false);
+        d[1].epi.bias = B.b[1];
+        if (!P.tp1) {
+            if (P.m1 == 1) d[1].epi.bn = bn_eval_affine(B.bn1);
+            d[1].epi.relu = 1;
+        }
+        // conv3x1_2 (dilated) + ReLU
+        conv1d_desc(d[2], P.t2, B.w[2], t3, N, C, H, W, 0, B.dil, false);
+        d[2].epi.bias = B.b[2]; d[2].epi.relu = 1;
+        // conv1x3_2 (dilated) [+ BN2] [+ dropout] + residual + ReLU
+        conv1d_desc(d[3], t3, B.w[3], P.tp2 ? P.p4 : B.y, N, C, H, W, 1, B.dil, false);
+        d[3].epi.bias = B.b[3];
+        if (!P.tp2) {
+            if (P.m2 == 1) d[3].epi.bn = bn_eval_affine(B.bn2);
+            d[3].epi.nscale = B.drop_scale;
+            d[3].epi.res = xin; d[3].epi.res_C = C; d[3].epi.res_coff = 0;
+            d[3].epi.relu = 1;
+        }
+        P.pair12 = P.tp1 ? 0 : pair_variant(d[1], d[2]);
+        if (P.pair12 && !B.save) {
+            // the pair reads neighbouring columns of t1 while other blocks write their columns of
+            // t3: the two must not share a buffer; the intermediate's buffer is free (it stays in LDS)
+            d[2].out = P.p2;
+            d[3].in = P.p2;
+        }
+        P.pair_next = 0;
+    }
+    // conv1x3_2 of block i with conv3x1_1 of block i+1 (their buffers must not alias)
+    for (int i = 0; i + 1 < nb; ++i) {
+        Nb1dPlan &P = plan[i];
+        const IgemmDesc &a = P.d[3], &b = plan[i + 1].d[0];
+        if (P.tp2 || b.out == a.in) continue;
+        P.pair_next = pair_variant(a, b);
+    }
+    for (int i = 0; i < nb; ++i) {
+        Nb1dPlan &P = plan[i];
+        PackDesc *k = pk + 4 * i;
+        // (a block whose conv3x1_1 runs in the previous block's pair got its slot 0 filled there)
+        if (!(i > 0 && plan[i - 1].pair_next) && plan_igemm(P.d[0], ar, k[0])) return 1;
+        if (P.pair12) {
+            if (plan_pair(P.d[1], P.d[2], blk[i].save != nullptr, ar, k + 1, P.pd12)) return 1;
+        } else if (plan_igemm(P.d[1], ar, k[1]) || plan_igemm(P.d[2], ar, k[2])) return 1;
+        if (P.pair_next) {
+            PackDesc two[2];
+            if (plan_pair(P.d[3], plan[i + 1].d[0], true, ar, two, P.pdn)) return 1;
+            k[3] = two[0];
+            k[4] = two[1];          // slot 0 of the next block
+        } else if (plan_igemm(P.d[3], ar, k[3])) return 1;
+    }
+    for (int i = 0; i < nb; i += 1)
+        if (launch_pack(pk + 4 * i, 4, st)) return 1;      // one launch repacks a block's weight tensors
+
+    for (int i = 0; i < nb; ++i) {
+        const erf_nb1d_block_t &B = blk[i];
+        Nb1dPlan &P = plan[i];
+        const float *xin = i ? blk[i - 1].y : x;
+        if (!(i > 0 && plan[i - 1].pair_next) && run_igemm(P.d[0], st)) return 1;
+        if (P.pair12) {
+            if (run_pair(P.pd12, C, P.pair12, st)) return 1;
+        } else {
+            if (run_igemm(P.d[1], st)) return 1;
+            if (P.tp1) {
+                if (P.m1 == 2) { if (bn_train_stats(B.bn1, P.p2, M, C, ar, st)) return 1; }
+                else if (bn_eval_prepare(B.bn1, C, st)) return 1;
+                Epilogue e = kNoEpi;
+                e.bn = P.m1 == 2 ? bn_saved_affine(B.bn1) : bn_eval_affine(B.bn1);
+                e.relu = 1;
+                if (launch_elt(P.p2, P.t2, e, M, C, H * W, st)) return 1;
+            }
+            if (run_igemm(P.d[2], st)) return 1;
+        }
+        if (P.pair_next) {
+            if (run_pair(P.pdn, C, P.pair_next, st)) return 1;
+            continue;
+        }
+        if (run_igemm(P.d[3], st)) return 1;
+        if (P.tp2) {
+            if (P.m2 == 2) { if (bn_train_stats(B.bn2, P.p4, M, C, ar, st)) return 1; }
+            else if (bn_eval_prepare(B.bn2, C, st)) return 1;
+            Epilogue e = kNoEpi;
+            e.bn = P.m2 == 2 ? bn_saved_affine(B.bn2) : bn_eval_affine(B.bn2);
+            e.nscale = B.drop_scale;
+            e.res = xin; e.res_C = C; e.res_coff = 0;
+            e.relu = 1;
+            if (launch_elt(P.p4, B.y, e, M, C, H * W, st)) return 1;
+        }
+    }
+    return 0;
+}
+}  // namespace
+
+int erf_nb1d_chain_forward(const float *x, const erf_nb1d_block_t *blocks, int nblocks, int N, int C,
+                           int H, int W, void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4) return fail("non_bottleneck_1d: chann must be a multiple of 4 (got %d)", C);
+    if (nblocks < 1 || !blocks) return fail("non_bottleneck_1d chain: no blocks");
+    for (int i = 0; i < nblocks; ++i)
+        if (!blocks[i].y) return fail("non_bottleneck_1d chain: block %d has no output buffer", i);
+    // segments of kMaxChain blocks; the stream orders a segment's kernels behind the previous
+    // segment's, so each segment may reuse the workspace from its start
+    for (int i = 0; i < nblocks; i += kMaxChain) {
+        Arena ar(ws, ws_bytes);
+        const int nb = nblocks - i < kMaxChain ? nblocks - i : kMaxChain;
+        if (nb1d_chain_segment(i ? blocks[i - 1].y : x, blocks + i, nb, N, C, H, W, ar, st)) return 1;
+    }
+    return 0;
+}
+
 int erf_nb1d_forward(const float *x, const float *const w[4], const float *const b[4],
                      const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil, float *y,
                      float *const save[5], int N, int C, int H, int W, void *ws, size_t ws_bytes,
                      void *stream)
 {
-    hipStream_t st = (hipStream_t)stream;
-    Arena ar(ws, ws_bytes);
-    if (C % 4) return fail("non_bottleneck_1d: chann must be a multiple of 4 (got %d)", C);
-    if (dil < 1) return fail("non_bottleneck_1d: dilation must be >= 1");
-    const long long M = (long long)N * H * W;
-    const size_t nel = (size_t)M * C;
-    const int m1 = bn_mode(bn1), m2 = bn_mode(bn2);
-    // Two-pass BatchNorm (conv -> pre, [statistics,] normalise) in train mode and whenever the
-    // activations are saved for backward; eval-mode inference folds BN into the conv epilogue.
-    const bool tp1 = m1 == 2 || (m1 == 1 && save), tp2 = m2 == 2 || (m2 == 1 && save);
-    float *t1, *p2, *t2, *t3, *p4;
-    if (save) {
-        t1 = save[0]; p2 = save[1]; t2 = save[2]; t3 = save[3]; p4 = save[4];
-        if ((m1 && !p2) || (m2 && !p4)) return fail("non_bottleneck_1d: BatchNorm needs the pre2/pre4 buffers");
-    } else {
-        float *a = ar.floats(nel), *c = ar.floats(nel);
-        if (!a || !c) return fail("non_bottleneck_1d: workspace too small");
-        t1 = a; p2 = c; t2 = c; t3 = a; p4 = c;
-    }
-    IgemmDesc d[4];
-    PackDesc pk[4];
-    // conv3x1_1 + ReLU
-    conv1d_desc(d[0], x, w[0], t1, N, C, H, W, 0, 1, false);
-    d[0].epi.bias = b[0]; d[0].epi.relu = 1;
-    // conv1x3_1 [+ BN1] + ReLU
-    conv1d_desc(d[1], t1, w[1], tp1 ? p2 : t2, N, C, H, W, 1, 1, false);
-    d[1].epi.bias = b[1];
-    if (!tp1) {
-        if (m1 == 1) d[1].epi.bn = bn_eval_affine(bn1);
-        d[1].epi.relu = 1;
-    }
-    // conv3x1_2 (dilated) + ReLU
-    conv1d_desc(d[2], t2, w[2], t3, N, C, H, W, 0, dil, false);
-    d[2].epi.bias = b[2]; d[2].epi.relu = 1;
-    // conv1x3_2 (dilated) [+ BN2] [+ dropout] + residual + ReLU
-    conv1d_desc(d[3], t3, w[3], tp2 ? p4 : y, N, C, H, W, 1, dil, false);
-    d[3].epi.bias = b[3];
-    if (!tp2) {
-        if (m2 == 1) d[3].epi.bn = bn_eval_affine(bn2);
-        d[3].epi.nscale = drop_scale;
-        d[3].epi.res = x; d[3].epi.res_C = C; d[3].epi.res_coff = 0;
-        d[3].epi.relu = 1;
-    }
-    // conv1x3_1 -> conv3x1_2 as one launch over image columns when nothing sits between them
-    const int pair12 = tp1 ? 0 : pair_variant(d[1], d[2]);
-    PairDesc pd12;
-    if (pair12 && !save) {
-        // the pair reads neighbouring columns of t1 while other blocks write their columns of t3:
-        // the two must not share a buffer; the intermediate's buffer is free (it stays in LDS)
-        d[2].out = p2;
-        d[3].in = p2;
-    }
-    if (pair12) {
-        if (plan_igemm(d[0], ar, pk[0]) || plan_igemm(d[3], ar, pk[3])) return 1;
-        if (plan_pair(d[1], d[2], save != nullptr, ar, pk + 1, pd12)) return 1;
-    } else {
-        for (int i = 0; i < 4; ++i)
-            if (plan_igemm(d[i], ar, pk[i])) return 1;
-    }
-    if (launch_pack(pk, 4, st)) return 1;      // one launch repacks all four weight tensors
-
-    if (run_igemm(d[0], st)) return 1;
-    if (pair12) {
-        if (run_pair(pd12, C, pair12, st)) return 1;
-    } else {
-        if (run_igemm(d[1], st)) return 1;
-        if (tp1) {
-            if (m1 == 2) { if (bn_train_stats(bn1, p2, M, C, ar, st)) return 1; }
-            else if (bn_eval_prepare(bn1, C, st)) return 1;
-            Epilogue e = kNoEpi;
-            e.bn = m1 == 2 ? bn_saved_affine(bn1) : bn_eval_affine(bn1);
-            e.relu = 1;
-            if (launch_elt(p2, t2, e, M, C, H * W, st)) return 1;
-        }
-        if (run_igemm(d[2], st)) return 1;
-    }
-    if (run_igemm(d[3], st)) return 1;
-    if (tp2) {
-        if (m2 == 2) { if (bn_train_stats(bn2, p4, M, C, ar, st)) return 1; }
-        else if (bn_eval_prepare(bn2, C, st)) return 1;
-        Epilogue e = kNoEpi;
-        e.bn = m2 == 2 ? bn_saved_affine(bn2) : bn_eval_affine(bn2);
-        e.nscale = drop_scale;
-        e.res = x; e.res_C = C; e.res_coff = 0;
-        e.relu = 1;
-        if (launch_elt(p4, y, e, M, C, H * W, st)) return 1;
-    }
-    return 0;
+    erf_nb1d_block_t blk;
+    for (int i = 0; i < 4; ++i) { blk.w[i] = w[i]; blk.b[i] = b[i]; }
+    blk.bn1 = bn1; blk.bn2 = bn2; blk.drop_scale = drop_scale; blk.dil = dil; blk.y = y; blk.save = save;
+    return erf_nb1d_chain_forward(x, &blk, 1, N, C, H, W, ws, ws_bytes, stream);
 }
 
 int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,

@@ -19,7 +19,7 @@ except ImportError:  # imported as a top-level module next to the reference's sc
     from erfnet_pytorch_amd import functional as hipf
 
 __all__ = ["DownsamplerBlock", "non_bottleneck_1d", "UpsamplerBlock", "SoftMaxConv",
-           "DecoderBlockSmall", "DecoderBlock", "LadderBlock"]
+           "DecoderBlockSmall", "DecoderBlock", "LadderBlock", "run_layers"]
 
 _BN_EPS = 1e-3
 
@@ -104,16 +104,21 @@ class non_bottleneck_1d(nn.Module):
     def _dropout_enabled(self):
         return self.use_dropout and self.dropout.p != 0
 
+    def _gpu_args(self, input):
+        """Keyword arguments of functional.nb1d for this block (draws the dropout mask)."""
+        convs = [getattr(self, n) for n in self._CONVS]
+        mode = _bn_mode(self, self.use_batchnorm)
+        scale = _dropout2d_scale(input, self.dropout.p, self._dropout_enabled() and self.training)
+        return dict(weights=[c.weight for c in convs], biases=[c.bias for c in convs],
+                    dilated=self.dilated, bn1=_bn_args(self.bn1), bn2=_bn_args(self.bn2), bn_mode=mode,
+                    drop_scale=scale, momentum=self.bn1.momentum, eps=self.bn1.eps)
+
     def forward(self, input):
         if input.is_cuda:
-            convs = [getattr(self, n) for n in self._CONVS]
-            mode = _bn_mode(self, self.use_batchnorm)
-            scale = _dropout2d_scale(input, self.dropout.p, self._dropout_enabled() and self.training)
-            out = hipf.nb1d(input, [c.weight for c in convs], [c.bias for c in convs], self.dilated,
-                            _bn_args(self.bn1), _bn_args(self.bn2), mode, scale,
-                            momentum=self.bn1.momentum, eps=self.bn1.eps)
-            _bn_tick(self.bn1, mode)
-            _bn_tick(self.bn2, mode)
+            kw = self._gpu_args(input)
+            out = hipf.nb1d(input, kw.pop("weights"), kw.pop("biases"), kw.pop("dilated"), **kw)
+            _bn_tick(self.bn1, kw["bn_mode"])
+            _bn_tick(self.bn2, kw["bn_mode"])
             return out
         t = F.relu(self.conv3x1_1(input))
         t = self.conv1x3_1(t)
@@ -125,6 +130,39 @@ class non_bottleneck_1d(nn.Module):
         if self._dropout_enabled():
             t = self.dropout(t)
         return F.relu(t + input)
+
+
+def _plain_call(m):
+    """True when calling m.forward directly equals m(...): no hooks are registered."""
+    return not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
+
+
+def run_layers(layers, x):
+    """``for layer in layers: x = layer(x)`` (reference train/net_classification.py:32-36, 42-45).
+    On a GPU, runs of consecutive non_bottleneck_1d blocks of one width go to the library as one
+    chain (functional.nb1d_chain), which lets it schedule the last convolution of a block and the
+    first of the next as a single launch; the values are the same as block-by-block calls."""
+    layers = list(layers)
+    i = 0
+    while i < len(layers):
+        j = i
+        if x.is_cuda:
+            while (j < len(layers) and isinstance(layers[j], non_bottleneck_1d) and _plain_call(layers[j])
+                   and type(layers[j]).forward is non_bottleneck_1d.forward
+                   and layers[j].conv3x1_1.in_channels == x.shape[1]):
+                j += 1
+        if j - i >= 2:
+            run = layers[i:j]
+            x = hipf.nb1d_chain(x, [m._gpu_args(x) for m in run])
+            for m in run:
+                mode = _bn_mode(m, m.use_batchnorm)
+                _bn_tick(m.bn1, mode)
+                _bn_tick(m.bn2, mode)
+            i = j
+        else:
+            x = layers[i](x)
+            i += 1
+    return x
 
 
 class UpsamplerBlock(nn.Module):
@@ -192,9 +230,7 @@ class DecoderBlockSmall(nn.Module):
         ])
 
     def forward(self, input):
-        for layer in self.layers:
-            input = layer(input)
-        return input
+        return run_layers(self.layers, input)
 
 
 class DecoderBlock(DecoderBlockSmall):

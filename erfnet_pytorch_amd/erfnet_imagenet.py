@@ -22,8 +22,7 @@ class Encoder(nn.Module):
 
     def forward(self, input):
         t = self.initial_block(input)
-        for layer in self.layers:
-            t = layer(t)
+        t = _nets.run_layers(self.layers, t)
         return t
 
 

@@ -23,8 +23,7 @@ class Encoder(nn.Module):
 
     def forward(self, input, predict=False):
         t = self.initial_block(input)
-        for layer in self.layers:
-            t = layer(t)
+        t = _nets.run_layers(self.layers, t)
         return _nets.conv1x1(self.output_conv, t) if predict else t
 
 
@@ -37,8 +36,7 @@ class Decoder(nn.Module):
         self.output_conv = _nets.OutputConvTranspose(16, num_classes)
 
     def forward(self, input):
-        for layer in self.layers:
-            input = layer(input)
+        input = _nets.run_layers(self.layers, input)
         return self.output_conv(input)
 
 

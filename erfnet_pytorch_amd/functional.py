@@ -324,6 +324,134 @@ def nb1d(x, weights, biases, dilated, bn1=None, bn2=None, bn_mode=0, drop_scale=
                                    drop_scale, dilated, bn_mode, momentum, eps, tok), tok)
 
 
+class _Nb1dChain(torch.autograd.Function):
+    """A run of non_bottleneck_1d blocks as one autograd node: the forward hands the whole run to
+    erf_nb1d_chain_forward, the backward walks the blocks in reverse through erf_nb1d_backward and
+    passes the ReLU mask of each block's input gradient along (the run knows its own wiring)."""
+
+    PER_BLOCK = 12      # w0 b0 w1 b1 w2 b2 w3 b3 g1 be1 g2 be2
+
+    @staticmethod
+    def forward(ctx, x, meta, out_token, *flat):
+        lib = _lib.lib()
+        ctx.in_token = _input_token(x)
+        ctx.out_token = out_token
+        x = _nhwc(x)
+        n, c, h, wd = x.shape
+        nb = len(meta)
+        need = out_token.grad_on and any(ctx.needs_input_grad)
+        blocks = (_lib.Nb1dBlockStruct * nb)()
+        keep = []           # python objects that must outlive the call (ctypes arrays, BN structs)
+        per_block = []
+        for i, m in enumerate(meta):
+            w0, b0, w1, b1, w2, b2, w3, b3, g1, be1, g2, be2 = flat[i * 12:(i + 1) * 12]
+            ws_ = [_param(t) for t in (w0, w1, w2, w3)]
+            bs_ = [_param(t) for t in (b0, b1, b2, b3)]
+            mode = m["mode"]
+            bn1 = _Bn(mode, g1, be1, m["rm1"], m["rv1"], m["momentum"], m["eps"], need)
+            bn2 = _Bn(mode, g2, be2, m["rm2"], m["rv2"], m["momentum"], m["eps"], need)
+            ds = m["drop_scale"]
+            ds = None if ds is None else ds.to(torch.float32).contiguous()
+            y = torch.empty_like(x)
+            save = None
+            if need:
+                save = [torch.empty_like(x), torch.empty_like(x) if mode else None, torch.empty_like(x),
+                        torch.empty_like(x), torch.empty_like(x) if mode else None]
+            B = blocks[i]
+            for k in range(4):
+                B.w[k] = ws_[k].data_ptr()
+                B.b[k] = bs_[k].data_ptr()
+            if mode:
+                B.bn1 = C.pointer(bn1.struct)
+                B.bn2 = C.pointer(bn2.struct)
+            B.drop_scale = _p(ds)
+            B.dil = int(m["dil"])
+            B.y = y.data_ptr()
+            if save is not None:
+                arr = _arr(save)
+                keep.append(arr)
+                B.save = C.cast(arr, C.POINTER(vp))
+            keep += [bn1, bn2, ws_, bs_, ds]
+            per_block.append((y, save, ws_, bn1, bn2, ds))
+        ws = _workspace(x, n * h * wd, c)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_nb1d_chain_forward(_p(x), blocks, nb, n, c, h, wd, _p(ws), ws.numel(),
+                                                  _stream(x)))
+        if need:
+            tensors = [x]
+            for y, save, ws_, bn1, bn2, ds in per_block:
+                tensors += [y, *save, *ws_, bn1.gamma, bn2.gamma, bn1.save_mean, bn1.save_invstd,
+                            bn2.save_mean, bn2.save_invstd, ds]
+            ctx.save_for_backward(*tensors)
+            ctx.cfg = [(int(m["dil"]), m["mode"], m["momentum"], m["eps"]) for m in meta]
+            ctx.params = flat
+        return per_block[-1][0]
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        saved = ctx.saved_tensors
+        x0 = saved[0]
+        n, c, h, wd = x0.shape
+        nb = len(ctx.cfg)
+        per = 17            # tensors saved per block
+        gy = _nhwc(gy)
+        last_flags = _bwd_flags(ctx, gy)
+        grads = [None] * (nb * 12)
+        ws = _workspace(x0, n * h * wd, c)
+        for i in reversed(range(nb)):
+            (y, t1, p2, t2, t3, p4, w0, w1, w2, w3, g1, g2, sm1, si1, sm2, si2, ds) = saved[1 + i * per:1 + (i + 1) * per]
+            x = saved[1 + (i - 1) * per] if i else x0
+            dil, mode, momentum, eps = ctx.cfg[i]
+            bn1 = _Bn(mode, g1, None, None, None, momentum, eps, False, saved=(sm1, si1))
+            bn2 = _Bn(mode, g2, None, None, None, momentum, eps, False, saved=(sm2, si2))
+            dx = torch.empty_like(x)
+            cvec = (c,) if mode else None
+            params = ctx.params[i * 12:(i + 1) * 12]
+            tg = _grad_targets(params, (w0.shape, (c,), w1.shape, (c,), w2.shape, (c,), w3.shape, (c,),
+                                        cvec, cvec, cvec, cvec), x.device)
+            dws = [tg[k][0] for k in (0, 2, 4, 6)]
+            dbs = [tg[k][0] for k in (1, 3, 5, 7)]
+            dgs, dbts = [tg[8][0], tg[10][0]], [tg[9][0], tg[11][0]]
+            # inside the run every block masks the gradient it hands to its producer, which then
+            # skips its own masking pass; the ends follow the neighbours outside the run
+            if i == nb - 1:
+                flags = last_flags & _lib.BWD_GY_PREMASKED
+            else:
+                flags = _lib.BWD_GY_PREMASKED
+            if i > 0 or ctx.in_token is not None:
+                flags |= _lib.BWD_MASK_DX
+            with _dev_ctx(x):
+                _lib.check(lib.erf_nb1d_backward(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
+                                                 dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
+                                                 _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
+                                                 flags, _p(ws), ws.numel(), _stream(x)))
+            grads[i * 12:(i + 1) * 12] = _deliver(tg)
+            gy = dx
+        return (_hand_over(ctx, gy), None, None, *grads)
+
+
+def nb1d_chain(x, blocks):
+    """``for b in blocks: x = nb1d(x, **b)`` as one call (reference: the layer loops of
+    train/net_classification.py:32-36, 42-45).  Each element of ``blocks`` is a dict with the
+    arguments of :func:`nb1d`: weights, biases, dilated, and optionally bn1, bn2, bn_mode,
+    drop_scale, momentum, eps."""
+    meta, flat = [], []
+    for b in blocks:
+        mode = int(b.get("bn_mode", 0))
+        g1 = be1 = rm1 = rv1 = g2 = be2 = rm2 = rv2 = None
+        if mode:
+            g1, be1, rm1, rv1 = b["bn1"]
+            g2, be2, rm2, rv2 = b["bn2"]
+        meta.append({"dil": b["dilated"], "mode": mode, "momentum": b.get("momentum", 0.1),
+                     "eps": b.get("eps", 1e-3), "drop_scale": b.get("drop_scale"),
+                     "rm1": rm1, "rv1": rv1, "rm2": rm2, "rv2": rv2})
+        w, bi = b["weights"], b["biases"]
+        flat += [w[0], bi[0], w[1], bi[1], w[2], bi[2], w[3], bi[3], g1, be1, g2, be2]
+    tok = _ReluToken()
+    return _tag_output(_Nb1dChain.apply(x, meta, tok, *flat), tok)
+
+
 # ------------------------------------------------------------------------------ UpsamplerBlock
 class _Upsampler(torch.autograd.Function):
     @staticmethod

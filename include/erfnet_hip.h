@@ -102,6 +102,23 @@ int erf_nb1d_forward(const float *x, const float *const w[4], const float *const
                      const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil,
                      float *y, float *const save[5], int N, int C, int H, int W, void *ws,
                      size_t ws_bytes, void *stream);
+
+/* A run of consecutive non_bottleneck_1d blocks of one channel count and resolution, as the
+ * encoders and decoders apply them (train/net_classification.py:32-36, 42-45: "for layer in
+ * self.layers: output = layer(output)"): y_0 = block_0(x), y_i = block_i(y_{i-1}).  The results
+ * equal nblocks calls of erf_nb1d_forward bit for bit; handing the run over at once lets the
+ * library schedule the last convolution of a block and the first of the next as one launch.
+ * Members as the arguments of erf_nb1d_forward; every block's y is written. */
+typedef struct {
+    const float *w[4], *b[4];
+    const erf_bn_t *bn1, *bn2;
+    const float *drop_scale;
+    int dil;
+    float *y;
+    float *const *save;
+} erf_nb1d_block_t;
+int erf_nb1d_chain_forward(const float *x, const erf_nb1d_block_t *blocks, int nblocks, int N, int C,
+                           int H, int W, void *ws, size_t ws_bytes, void *stream);
 /* dw[4]/db[4] (and dgamma[2]/dbeta[2] in BN modes) are overwritten; dx is required. */
 int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *bn1,
                       const erf_bn_t *bn2, const float *drop_scale, int dil, const float *y,
