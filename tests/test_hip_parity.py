@@ -500,6 +500,77 @@ def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
         assert torch.equal(u, v), f"tensor {i}"
 
 
+@pytest.mark.parametrize("C_,N,H,W,nblocks", [(128, 1, 64, 24, 3), (64, 2, 72, 20, 2), (16, 1, 16, 32, 2),
+                                              (128, 1, 40, 16, 10)])
+@pytest.mark.parametrize("bn_mode,dropout", [(0, False), (2, False), (1, True), (0, True)])
+def test_nb1d_chain_equals_blockwise_calls(C_, N, H, W, nblocks, bn_mode, dropout):
+    """functional.nb1d_chain (erf_nb1d_chain_forward + per-block backward) must give bit-identical
+    outputs, input gradient, parameter gradients and running statistics to calling the blocks one
+    after the other — including runs longer than the library's segment length, BatchNorm in both
+    modes and Dropout2d factors (which keep a block's tail out of the shared launch)."""
+    from erfnet_pytorch_amd import functional as hipf
+    g = torch.Generator(device="cpu").manual_seed(C_ * 7 + nblocks)
+    x = torch.randn(N, C_, H, W, generator=g).clamp_(min=0).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, C_, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    dils = [1, 2, 4, 8, 16, 1, 2, 3, 1, 5][:nblocks]
+    blocks = []
+    for i in range(nblocks):
+        ws = [(torch.randn(C_, C_, *k, generator=g) * (0.5 / C_ ** 0.5)).to(DEV).requires_grad_(True)
+              for k in ((3, 1), (1, 3), (3, 1), (1, 3))]
+        bs = [(torch.randn(C_, generator=g) * 0.1).to(DEV).requires_grad_(True) for _ in range(4)]
+        b = dict(weights=ws, biases=bs, dilated=dils[i])
+        if bn_mode:
+            b["bn_mode"] = bn_mode
+            for key in ("bn1", "bn2"):
+                b[key] = ((torch.rand(C_, generator=g) + 0.5).to(DEV).requires_grad_(True),
+                          (torch.randn(C_, generator=g) * 0.1).to(DEV).requires_grad_(True),
+                          (torch.randn(C_, generator=g) * 0.1).to(DEV), (torch.rand(C_, generator=g) + 0.5).to(DEV))
+        if dropout and i % 2 == 0:
+            b["drop_scale"] = (torch.rand(N, C_, generator=g) > 0.3).float().div(0.7).to(DEV)
+        blocks.append(b)
+
+    def leaves():
+        out = []
+        for b in blocks:
+            out += b["weights"] + b["biases"]
+            if bn_mode:
+                out += [b["bn1"][0], b["bn1"][1], b["bn2"][0], b["bn2"][1]]
+        return out
+
+    def stats():
+        return [t for b in blocks if bn_mode for key in ("bn1", "bn2") for t in b[key][2:]]
+
+    stats0 = [t.clone() for t in stats()]
+    res = []
+    for chained in (False, True):
+        for t, t0 in zip(stats(), stats0):
+            t.copy_(t0)
+        for q in leaves():
+            q.grad = None
+        xx = x.clone().requires_grad_(True)
+        n0 = launches()
+        if chained:
+            y = hipf.nb1d_chain(xx, blocks)
+        else:
+            y = xx
+            for b in blocks:
+                kw = dict(b)
+                y = hipf.nb1d(y, kw.pop("weights"), kw.pop("biases"), kw.pop("dilated"), **kw)
+        y.backward(gy)
+        got = [y.detach(), xx.grad] + [q.grad.clone() for q in leaves()] + [t.clone() for t in stats()]
+        with torch.no_grad():
+            yi = hipf.nb1d_chain(x, blocks) if chained else None
+        res.append((got, launches() - n0, yi))
+    for i, (u, v) in enumerate(zip(res[0][0], res[1][0])):
+        assert torch.equal(u, v), f"tensor {i}"
+    # inference under no_grad: the training forward's values (eval-mode BatchNorm is folded into
+    # the convolution epilogue there, which rounds differently)
+    if bn_mode == 0:
+        assert torch.equal(res[1][2], res[0][0][0])
+    elif bn_mode == 1:
+        assert torch.allclose(res[1][2], res[0][0][0], rtol=1e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------- full benchmark size: properties
 def _torch_nb1d(x, ws, bs, d):
     import torch.nn.functional as F
