@@ -160,41 +160,61 @@ __global__ __launch_bounds__(256, (BM * NC <= 8192 ? 3 : 2)) void pair_f32_kerne
 
     // ------------------------------------------------------------------ epilogues
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // All loads of an epilogue (residual, mask) are issued before the first store: the compiler
+    // must assume that a store may alias a later load, so interleaving them would expose one
+    // memory latency per group of rows.  Absent tensors are skipped with wave-uniform branches.
     auto epilogue = [&](const Epilogue &e, float sc, float sh, float *dst, bool to_lds) {
         const __amdgpu_buffer_rsrc_t r_out = make_rsrc(dst, P * NC * 4u);
         const __amdgpu_buffer_rsrc_t r_res = make_rsrc(e.res, P * e.res_C * 4u);
         const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(e.mask, P * e.mask_C * 4u);
-        const bool has_mask = e.mask != nullptr, relu = e.relu != 0;
+        const bool has_mask = e.mask != nullptr, has_res = e.res != nullptr, relu = e.relu != 0;
+        // row of accumulator element r: a wave-uniform part (scalar offset operand of the buffer
+        // instructions) plus 4 * (lane >> 5) (part of the per-lane offset)
+        auto urow = [&](int a, int r) { return (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2); };
+        const unsigned px0 = base + (unsigned)(4 * h * d.pstride);
+        float rres[WM][16], rmask[WM][16];
 #pragma unroll
-        for (int a = 0; a < WM; ++a) {
+        for (int a = 0; a < WM; ++a)
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                unsigned opx[8], rbad[8];
-                int rw[8];
+            for (int r = 0; r < 16; ++r) { rres[a][r] = 0.0f; rmask[a][r] = 1.0f; }
+        // rows beyond the line need no guard on the load side: the value is not used, and an
+        // address past the tensor is out of range for the descriptor
+        if (has_res) {
+            const unsigned voff = (px0 * e.res_C + e.res_coff + col) * 4u;
+            const unsigned rowb = (unsigned)(d.pstride * e.res_C) * 4u;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = hf * 8 + k;
-                    rw[k] = (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    opx[k] = base + (unsigned)(rw[k] * d.pstride);
-                    rbad[k] = (unsigned)((L - 1 - rw[k]) >> 31) & ERF_OOB;
-                }
-                float rres[8], rmask[8];
+            for (int a = 0; a < WM; ++a)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    rres[k] = buf_load1(r_res, ((opx[k] * e.res_C + e.res_coff + col) * 4u) | rbad[k]);
-                    rmask[k] = buf_load1(r_mask, ((opx[k] * e.mask_C + e.mask_coff + col) * 4u) | rbad[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    float v = acc[a][hf * 8 + k] * sc + sh;
-                    v += rres[k];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    v = (!has_mask || rmask[k] > 0.0f) ? v : 0.0f;
-                    buf_store1(r_out, ((opx[k] * NC + col) * 4u) | rbad[k], v);
-                    if (to_lds) Ts[rw[k] * NC + (mid_swz(rw[k], col >> 2) << 2) + (col & 3)] = v;
-                }
-            }
+                for (int r = 0; r < 16; ++r)
+                    rres[a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        r_res, (int)voff, (int)__builtin_amdgcn_readfirstlane(urow(a, r) * rowb), 0));
         }
+        if (has_mask) {
+            const unsigned voff = (px0 * e.mask_C + e.mask_coff + col) * 4u;
+            const unsigned rowb = (unsigned)(d.pstride * e.mask_C) * 4u;
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    rmask[a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        r_mask, (int)voff, (int)__builtin_amdgcn_readfirstlane(urow(a, r) * rowb), 0));
+        }
+        const unsigned ovoff = (px0 * NC + col) * 4u;
+        const unsigned orowb = (unsigned)(d.pstride * NC) * 4u;
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rw = urow(a, r) + 4 * h;
+                float v = acc[a][r] * sc + sh;
+                v += rres[a][r];
+                if (relu) v = fmaxf(v, 0.0f);
+                v = rmask[a][r] > 0.0f ? v : 0.0f;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_out,
+                                                      (int)(ovoff | ((unsigned)((L - 1 - rw) >> 31) & ERF_OOB)),
+                                                      (int)__builtin_amdgcn_readfirstlane(urow(a, r) * orowb), 0);
+                if (to_lds) Ts[rw * NC + (mid_swz(rw, col >> 2) << 2) + (col & 3)] = v;
+            }
     };
 
     // conv_b's first two weight tiles travel while the first epilogue runs
