@@ -76,6 +76,9 @@ _PROTOS = {
                                    C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_nb1d_chain_forward": (C.c_int, [vp, C.POINTER(Nb1dBlockStruct), C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, vp, C.c_size_t, vp]),
+    "erf_conv_pair_pack": (C.c_int, [vp, vp, C.c_int, vp, vp]),
+    "erf_conv_pair_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                        vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "erf_nb1d_backward": (C.c_int, [vp, C.POINTER(vp), C.POINTER(BnStruct), C.POINTER(BnStruct), vp,
                                     C.c_int, vp, C.POINTER(vp), vp, vp, C.POINTER(vp),
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,

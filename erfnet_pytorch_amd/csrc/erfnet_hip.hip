@@ -1045,6 +1045,62 @@ int erf_nb1d_forward(const float *x, const float *const w[4], const float *const
     return erf_nb1d_chain_forward(x, &blk, 1, N, C, H, W, ws, ws_bytes, stream);
 }
 
+// ================================================================================ convolution pair
+int erf_conv_pair_pack(const float *w_first, const float *w_second, int C, float *packed, void *stream)
+{
+    if (C != 64 && C != 128) return fail("conv pair: 64 or 128 channels (got %d)", C);
+    if (!w_first || !w_second || !packed) return fail("conv pair: null weight pointer");
+    PackDesc pk[2];
+    const float *w[2] = {w_first, w_second};
+    for (int i = 0; i < 2; ++i) {
+        memset(&pk[i], 0, sizeof(PackDesc));
+        pk[i].w = w[i]; pk[i].wp = packed + (size_t)i * 3 * C * C;
+        pk[i].ntaps = 3; pk[i].K = C; pk[i].Nout = C; pk[i].Npad = C; pk[i].wsk = 3; pk[i].wsn = C * 3; pk[i].kc = 16;
+        for (int t = 0; t < 3; ++t) pk[i].woff[t] = t;
+    }
+    return launch_pack(pk, 2, (hipStream_t)stream);
+}
+
+int erf_conv_pair_forward(const float *x, const float *packed, const float *b_first, const float *b_second,
+                          int first_axis, int dil_first, int dil_second, int relu_first, int relu_second,
+                          const float *residual, float *mid, float *y, int N, int C, int H, int W,
+                          void *stream)
+{
+    if (first_axis != 0 && first_axis != 1) return fail("conv pair: first_axis is 0 (H) or 1 (W)");
+    if (dil_first < 1 || dil_second < 1) return fail("conv pair: dilation must be >= 1");
+    if (!x || !packed || !y) return fail("conv pair: null tensor pointer");
+    if (y == x || mid == x) return fail("conv pair: the outputs must not alias the input");
+    IgemmDesc a, b;
+    // descriptors only for the geometry checks of pair_variant; an unstored intermediate is
+    // given the input's (aligned) address there
+    float *link = mid ? mid : const_cast<float *>(x);
+    conv1d_desc(a, x, nullptr, link, N, C, H, W, first_axis, dil_first, false);
+    conv1d_desc(b, link, nullptr, y, N, C, H, W, 1 - first_axis, dil_second, false);
+    a.epi.bias = b_first; a.epi.relu = relu_first ? 1 : 0;
+    b.epi.bias = b_second; b.epi.relu = relu_second ? 1 : 0;
+    if (residual) { b.epi.res = residual; b.epi.res_C = C; }
+    const int saved = g_pair_on.load(std::memory_order_relaxed);
+    g_pair_on.store(1, std::memory_order_relaxed);
+    const int tile = pair_variant(a, b);
+    g_pair_on.store(saved, std::memory_order_relaxed);
+    if (!tile) return fail("conv pair: %d channels with lines of %d pixels have no fused kernel", C, first_axis ? H : W);
+    PairDesc pd;
+    memset(&pd, 0, sizeof(pd));
+    pd.in = x; pd.wp1 = packed; pd.wp2 = packed + (size_t)3 * C * C;
+    pd.mid = mid; pd.out = y;
+    pd.epi1 = a.epi; pd.epi2 = b.epi;
+    pd.N = N; pd.img_pixels = H * W;
+    if (first_axis == 1) {
+        pd.lines_per_img = W; pd.L = H; pd.pstride = W; pd.qstride = 1;
+        for (int t = 0; t < 3; ++t) { pd.s1[t] = a.tdw[t]; pd.s2[t] = b.tdh[t]; }
+    } else {
+        pd.lines_per_img = H; pd.L = W; pd.pstride = 1; pd.qstride = W;
+        for (int t = 0; t < 3; ++t) { pd.s1[t] = a.tdh[t]; pd.s2[t] = b.tdw[t]; }
+    }
+    pd.nlines = N * pd.lines_per_img;
+    return run_pair(pd, C, tile, (hipStream_t)stream);
+}
+
 int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
                       const float *drop_scale, int dil, const float *y, const float *const save[5],
                       const float *gy, float *dx, float *const dw[4], float *const db[4],

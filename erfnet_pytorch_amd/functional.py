@@ -452,6 +452,37 @@ def nb1d_chain(x, blocks):
     return _tag_output(_Nb1dChain.apply(x, meta, tok, *flat), tok)
 
 
+def conv_pair_pack(w_first, w_second):
+    """Repack the [C,C,3,1] / [C,C,1,3] weights of two chained 1-D convolutions for
+    :func:`conv_pair` (erf_conv_pair_pack); do it once per set of weights."""
+    c = w_first.shape[0]
+    wa, wb = _param(w_first), _param(w_second)
+    packed = torch.empty(2 * 3 * c * c, dtype=torch.float32, device=wa.device)
+    with _dev_ctx(wa):
+        _lib.check(_lib.lib().erf_conv_pair_pack(_p(wa), _p(wb), c, _p(packed), _stream(wa)))
+    return packed
+
+
+def conv_pair(x, packed, b_first, b_second, first_axis, dil_first=1, dil_second=1, relu_first=True,
+              relu_second=True, residual=None, keep_mid=False):
+    """Two chained 3-tap convolutions in one launch, inference only (no autograd graph):
+    ``mid = act(conv_first(x)); y = act(conv_second(mid) [+ residual])`` — the conv/relu/conv runs
+    of non_bottleneck_1d.forward (reference train/erfnet_blocks.py:57-66).  first_axis 1: (1,3) then
+    (3,1) kernels; 0: (3,1) then (1,3).  Returns y, or (y, mid) with keep_mid.  Raises when the
+    image geometry has no fused kernel."""
+    x = _nhwc(x.detach())
+    n, c, h, wd = x.shape
+    y = torch.empty_like(x)
+    mid = torch.empty_like(x) if keep_mid else None
+    res = None if residual is None else _nhwc(residual.detach())
+    with _dev_ctx(x):
+        _lib.check(_lib.lib().erf_conv_pair_forward(_p(x), _p(packed), _p(_param(b_first)), _p(_param(b_second)),
+                                                    int(first_axis), int(dil_first), int(dil_second),
+                                                    int(bool(relu_first)), int(bool(relu_second)), _p(res),
+                                                    _p(mid), _p(y), n, c, h, wd, _stream(x)))
+    return (y, mid) if keep_mid else y
+
+
 # ------------------------------------------------------------------------------ UpsamplerBlock
 class _Upsampler(torch.autograd.Function):
     @staticmethod

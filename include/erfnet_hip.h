@@ -126,6 +126,24 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
                       float *const db[4], float *const dgamma[2], float *const dbeta[2], int N,
                       int C, int H, int W, int flags, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- Two chained 1-D convolutions (train/erfnet_blocks.py:57-62 and 64-66: conv -> [relu] ->
+ *      conv of a non_bottleneck_1d), C -> C channels, 3 taps each, as ONE launch ------------------
+ * mid = act(conv_first(x) + b_first);  y = act(conv_second(mid) + b_second [+ residual])
+ * first_axis: 1 = the first convolution runs along W (kernel (1,3)) and the second along H
+ * (kernel (3,1)); 0 = the other way round.  A block computes a whole image line of the second
+ * convolution (a column for first_axis = 1), so that line must fit a tile: C = 128 with 33..128
+ * pixels per line, C = 64 with 65..256; otherwise the call is rejected
+ * and the caller uses erf_nb1d_forward, which picks the launch plan itself.
+ * Weights are repacked once with erf_conv_pair_pack (torch layout [C][C][3] each, `packed` holds
+ * 2*3*C*C floats) and may then serve any number of forward calls — at inference they never change.
+ * mid may be NULL (the intermediate then never leaves the chip).  x, mid, y, residual: NHWC, 16-byte
+ * aligned, y and mid distinct from x. */
+int erf_conv_pair_pack(const float *w_first, const float *w_second, int C, float *packed, void *stream);
+int erf_conv_pair_forward(const float *x, const float *packed, const float *b_first,
+                          const float *b_second, int first_axis, int dil_first, int dil_second,
+                          int relu_first, int relu_second, const float *residual, float *mid, float *y,
+                          int N, int C, int H, int W, void *stream);
+
 /* ---- UpsamplerBlock (train/erfnet_blocks.py:77-88; eval/erfnet.py:99-108) -------------------
  * y = relu([bn](ConvTranspose2d(Cin,Cout,3,stride 2,padding 1,output_padding 1)(x)))
  * x NHWC [N,Cin,H,W]; y, pre NHWC [N,Cout,2H,2W]; w [Cin][Cout][3][3]. */

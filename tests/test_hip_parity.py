@@ -571,6 +571,39 @@ def test_nb1d_chain_equals_blockwise_calls(C_, N, H, W, nblocks, bn_mode, dropou
         assert torch.allclose(res[1][2], res[0][0][0], rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("C_,N,H,W,axis,d1,d2", [(128, 2, 64, 40, 1, 1, 2), (128, 1, 40, 128, 0, 2, 2),
+                                                 (64, 1, 128, 24, 1, 4, 1), (64, 2, 20, 200, 0, 1, 3)])
+def test_conv_pair_c_abi_against_torch(C_, N, H, W, axis, d1, d2):
+    """erf_conv_pair_pack / erf_conv_pair_forward (both line orientations, stored and unstored
+    intermediate, residual) against stock torch fp32 convolutions: 1e-4 relative to the scale."""
+    import torch.nn.functional as F
+    from erfnet_pytorch_amd import functional as hipf
+    g = torch.Generator(device="cpu").manual_seed(C_ + H + W)
+    x = torch.randn(N, C_, H, W, generator=g).to(DEV)
+    res = torch.randn(N, C_, H, W, generator=g).to(DEV)
+    ka, kb = ((1, 3), (3, 1)) if axis == 1 else ((3, 1), (1, 3))
+    wa = (torch.randn(C_, C_, *ka, generator=g) * (0.6 / C_ ** 0.5)).to(DEV)
+    wb = (torch.randn(C_, C_, *kb, generator=g) * (0.6 / C_ ** 0.5)).to(DEV)
+    ba, bb = (torch.randn(C_, generator=g) * 0.1).to(DEV), (torch.randn(C_, generator=g) * 0.1).to(DEV)
+
+    def conv(t, w, b, d):
+        kh = w.shape[2]
+        return F.conv2d(t, w, b, padding=(d, 0) if kh == 3 else (0, d), dilation=(d, 1) if kh == 3 else (1, d))
+
+    mid_ref = F.relu(conv(x, wa, ba, d1))
+    y_ref = F.relu(conv(mid_ref, wb, bb, d2) + res)
+    packed = hipf.conv_pair_pack(wa, wb)
+    n0 = launches()
+    y, mid = hipf.conv_pair(x, packed, ba, bb, axis, d1, d2, True, True, residual=res, keep_mid=True)
+    y2 = hipf.conv_pair(x, packed, ba, bb, axis, d1, d2, True, True, residual=res)
+    assert launches() - n0 == 2
+    assert torch.equal(y, y2)
+    gu.check_arrays(mid.cpu().numpy(), mid_ref.cpu().numpy(), 1e-4, 1e-4, what="mid", scale_rtol=1e-4)
+    gu.check_arrays(y.cpu().numpy(), y_ref.cpu().numpy(), 1e-4, 1e-4, what="y", scale_rtol=1e-4)
+    with pytest.raises(RuntimeError):
+        hipf.conv_pair(x[:, :, :8, :8].contiguous(), packed, ba, bb, axis)
+
+
 # ------------------------------------------------------------- full benchmark size: properties
 def _torch_nb1d(x, ws, bs, d):
     import torch.nn.functional as F
