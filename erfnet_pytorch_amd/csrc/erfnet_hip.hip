@@ -6,6 +6,7 @@
 #include "stream16.h"
 #include "sampler16.h"
 #include "pair.h"
+#include "wgrad_line.h"
 #include "loss_kernels.h"
 
 #include <atomic>
@@ -363,6 +364,78 @@ int launch_reduce_batch(const WgradDesc *d, int n, float *const *dw, float *cons
     return 0;
 }
 
+// The 3-tap 1-D convolutions at 64 / 128 channels take wgrad_line_kernel (all taps per block, X and
+// G read once).  ERFNET_NO_WGRAD_LINE=1 keeps them on wgrad_f32_kernel (experiments).
+bool wgrad_line_ok(const WgradDesc *dd, int n)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("ERFNET_NO_WGRAD_LINE"); on = (e && atoi(e)) ? 0 : 1; }
+    if (!on) return false;
+    const int NC = dd[0].K;
+    if (NC != 64 && NC != 128) return false;
+    for (int i = 0; i < n; ++i) {
+        const WgradDesc &e = dd[i];
+        if (e.K != NC || e.Nout != NC || e.in_C != NC || e.g_C != NC || e.in_coff || e.g_coff) return false;
+        if (e.ntaps != 3 || e.ss != 1 || e.os != 1) return false;
+        if (e.in_H != e.GH || e.in_W != e.GW || e.g_H != e.GH || e.g_W != e.GW) return false;
+        bool along_h = true, along_w = true;
+        for (int t = 0; t < 3; ++t) {
+            if (e.toa[t] || e.tob[t]) return false;
+            along_h = along_h && e.tdw[t] == 0;
+            along_w = along_w && e.tdh[t] == 0;
+        }
+        const int *td = along_h ? e.tdh : e.tdw;
+        if (!(along_h || along_w) || td[1] != 0 || td[0] != -td[2] || td[2] < 1 || td[2] > 16) return false;
+        if ((long long)e.N * e.GH * e.GW * NC >= (1LL << 29)) return false;
+    }
+    return true;
+}
+
+int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, const int *woff, int wsk,
+                      int wsn, unsigned bias_taps, Arena &ar, hipStream_t st)
+{
+    const int NC = dd[0].K;
+    const long long M = (long long)dd[0].N * dd[0].GH * dd[0].GW;
+    if (M == 0) return 0;
+    const int jtiles = NC / 64;
+    const int slots = NC == 128 ? 512 : 768;                // resident blocks: 2 / 3 per CU
+    const size_t slab = (size_t)3 * NC * NC + 3 * NC;
+    WgradLineBatch wb;
+    memset(&wb, 0, sizeof(wb));
+    int nsplit = slots / (jtiles * n);
+    if (nsplit < 1) nsplit = 1;
+    for (int i = 0; i < n; ++i) {
+        WgradDesc &e = dd[i];
+        WgradLineDesc &q = wb.d[i];
+        const bool along_h = e.tdw[0] == 0 && e.tdw[2] == 0;
+        q.in = e.in; q.g = e.g;
+        q.N = e.N; q.img_pixels = e.GH * e.GW;
+        if (along_h) { q.Len = e.GH; q.lines_per_img = e.GW; q.pstride = e.GW; q.qstride = 1; q.dil = e.tdh[2]; }
+        else { q.Len = e.GW; q.lines_per_img = e.GH; q.pstride = 1; q.qstride = e.GW; q.dil = e.tdw[2]; }
+        q.segs_per_line = (q.Len + 63) / 64;
+        q.nseg = e.N * q.lines_per_img * q.segs_per_line;
+        if (nsplit > q.nseg) nsplit = q.nseg;
+    }
+    // every convolution of the batch gets the same number of slabs; a block whose segment range
+    // is empty writes a slab of zeros
+    for (int i = 0; i < n; ++i) {
+        WgradDesc &e = dd[i];
+        WgradLineDesc &q = wb.d[i];
+        q.spb = (q.nseg + nsplit - 1) / nsplit;
+        e.nsplit = nsplit;
+        e.partial = ar.floats(slab * nsplit);
+        if (!e.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit * n);
+        q.partial = e.partial;
+    }
+    const int max_split = nsplit;
+    dim3 grid((unsigned)max_split, jtiles, n);
+    if (NC == 128) wgrad_line_kernel<128, 1, 2, 4, 1, 2><<<grid, 256, 0, st>>>(wb);
+    else wgrad_line_kernel<64, 1, 1, 2, 2, 3><<<grid, 256, 0, st>>>(wb);
+    CHECK_LAUNCH("wgrad_line_kernel");
+    // the slab carries the column sums of G in bias row 0 only
+    return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps ? 1u : 0u, st);
+}
+
 int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db, const int *woff, int wsk,
                        int wsn, unsigned bias_taps, Arena &ar, hipStream_t st)
 {
@@ -403,6 +476,7 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
         }
         return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);
     }
+    if (vec && wgrad_line_ok(dd, n)) return launch_wgrad_line(dd, n, dw, db, woff, wsk, wsn, bias_taps, ar, st);
     int IBLK, JBLK, cfg, PM = 32;
     if (!vec) { IBLK = 32; JBLK = 32; cfg = 7; PM = 64; }
     else if (d.K > 64 && d.Nout > 64) { IBLK = 128; JBLK = 128; cfg = 0; }
