@@ -397,8 +397,10 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     const int NC = dd[0].K;
     const long long M = (long long)dd[0].N * dd[0].GH * dd[0].GW;
     if (M == 0) return 0;
-    const int jtiles = NC / 64;
-    const int slots = NC == 128 ? 512 : 768;                // resident blocks: 2 / 3 per CU
+    // 128 channels: one 512-thread block per CU owns all 128 x 128 x 3 outputs (X is staged once);
+    // 64 channels: three 256-thread blocks per CU
+    const int jtiles = 1;
+    const int slots = NC == 128 ? 256 : 768;
     const size_t slab = (size_t)3 * NC * NC + 3 * NC;
     WgradLineBatch wb;
     memset(&wb, 0, sizeof(wb));
@@ -429,7 +431,7 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     }
     const int max_split = nsplit;
     dim3 grid((unsigned)max_split, jtiles, n);
-    if (NC == 128) wgrad_line_kernel<128, 1, 2, 4, 1, 2><<<grid, 256, 0, st>>>(wb);
+    if (NC == 128) wgrad_line_kernel<128, 1, 2, 4, 2, 1><<<grid, 512, 0, st>>>(wb);
     else wgrad_line_kernel<64, 1, 1, 2, 2, 3><<<grid, 256, 0, st>>>(wb);
     CHECK_LAUNCH("wgrad_line_kernel");
     // the slab carries the column sums of G in bias row 0 only

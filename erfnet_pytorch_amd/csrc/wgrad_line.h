@@ -27,14 +27,14 @@ struct WgradLineBatch {
 };
 
 // NC channels on both sides; block tile = all NC input channels x JBLK = GJ*JB*32 output channels,
-// GI*IB*32 = NC.  grid = (slabs, NC / JBLK, convolutions).
+// GI*IB*32 = NC, 4 or 8 waves.  grid = (slabs, NC / JBLK, convolutions).
 template <int NC, int IB, int JB, int GI, int GJ, int MINB>
-__global__ __launch_bounds__(256, MINB) void wgrad_line_kernel(const WgradLineBatch batch)
+__global__ __launch_bounds__(GI *GJ * 64, MINB) void wgrad_line_kernel(const WgradLineBatch batch)
 {
     const WgradLineDesc &d = batch.d[blockIdx.z];
-    constexpr int L = 64, XR = 96, NT = 256;
+    constexpr int L = 64, XR = 96, NT = GI * GJ * 64;
     constexpr int IBLK = GI * IB * 32, JBLK = GJ * JB * 32;
-    static_assert(IBLK == NC && GI * GJ == 4, "tile shape");
+    static_assert(IBLK == NC && (GI * GJ == 4 || GI * GJ == 8), "tile shape");
     constexpr int XQ = IBLK / 4, GQ = JBLK / 4;             // float4 slots per row
     constexpr int XP = XR * XQ / NT, GP = L * GQ / NT;
     static_assert(XR * XQ % NT == 0 && L * GQ % NT == 0, "whole passes");
