@@ -8,6 +8,7 @@
 #include "pair.h"
 #include "wgrad_line.h"
 #include "loss_kernels.h"
+#include "metric_kernels.h"
 
 #include <atomic>
 #include <cstdarg>
@@ -1519,6 +1520,35 @@ int erf_cross_entropy_backward(const float *logits, const long long *target, con
     CeBwdDesc d = {logits, target, lse, stats, gy, dlogits, P, H * W, K, ignore_index};
     ce_bwd_kernel<<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     CHECK_LAUNCH("ce_bwd_kernel");
+    return 0;
+}
+
+// ================================================================================ iouEval counts
+int erf_iou_add_batch(const long long *pred, const long long *target, long long n_pixels, int n_classes,
+                      int ignore_index, long long *counts, void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (n_classes < 1 || n_classes > IOU_MAX_CLASSES) return fail("iouEval: 1..%d classes (got %d)", IOU_MAX_CLASSES, n_classes);
+    if (ignore_index >= n_classes || ignore_index < -1) return fail("iouEval: ignore index %d outside [-1, %d)", ignore_index, n_classes);
+    if (!pred || !target || !counts) return fail("iouEval: null pointer");
+    if (n_pixels <= 0) return 0;
+    IouDesc d;
+    d.pred = pred; d.target = target; d.n = n_pixels;
+    d.n_classes = n_classes;
+    d.counted = ignore_index < 0 ? n_classes : ignore_index;     // reference slices [:, :ignoreIndex]
+    d.ignore = ignore_index;
+    d.counts = counts;
+    if (d.counted == 0) return 0;
+    long long blocks = (n_pixels + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 1024) blocks = 1024;
+    d.blocks = (int)blocks;
+    d.partial = (unsigned *)ar.take((size_t)blocks * 3 * d.counted * sizeof(unsigned));
+    if (!d.partial) return fail("iouEval: workspace too small");
+    iou_count_kernel<<<(unsigned)blocks, 256, 0, st>>>(d);
+    CHECK_LAUNCH("iou_count_kernel");
+    iou_sum_kernel<<<1, 256, 0, st>>>(d);
+    CHECK_LAUNCH("iou_sum_kernel");
     return 0;
 }
 

@@ -193,6 +193,17 @@ int erf_cross_entropy_backward(const float *logits, const long long *target, con
                                const float *stats, const float *gy, float *dlogits, int N, int K, int H,
                                int W, long long ignore_index, void *stream);
 
+/* ---- iouEval.addBatch for label maps (train/iouEval.py:21-70, eval/iouEval.py) ------------------
+ * pred, target: int64 class indices, n_pixels each (the [N,1,H,W] tensors the scripts pass:
+ * `outputs.max(1)[1].unsqueeze(1)` and the label batch).  Classes [0, counted) are tallied, where
+ * counted = ignore_index, or n_classes when ignore_index = -1 (the reference slices the one-hot
+ * tensors to [:ignoreIndex]); a false positive on a pixel whose target is ignore_index is not
+ * counted.  counts: int64 [3][counted] = tp, fp, fn; the call ADDS this batch (zero it to reset).
+ * Exact integer arithmetic; IoU = tp / (tp + fp + fn + 1e-15) is left to the caller. */
+int erf_iou_add_batch(const long long *pred, const long long *target, long long n_pixels,
+                      int n_classes, int ignore_index, long long *counts, void *ws, size_t ws_bytes,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

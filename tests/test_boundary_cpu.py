@@ -164,3 +164,22 @@ def test_cross_entropy_loss2d_cpu_matches_torch():
     a = CrossEntropyLoss2d(weight=torch.ones(5))(x, lab)
     b = torch.nn.functional.cross_entropy(x, lab, ignore_index=-1)
     assert torch.equal(a, b)
+
+
+def test_iou_eval_class_cpu_matches_golden():
+    """The drop-in iouEval class on CPU label maps (the reference's one-hot formulation path)
+    reproduces the reference's own result; counters are CPU double tensors as in the reference."""
+    import torch
+    from erfnet_pytorch_amd.iouEval import iouEval, getColorEntry, colors
+    pred = torch.from_numpy(gu.det_labels("iou.pred", (2, 1, 32, 48), 0, 20).astype(np.int64))
+    lab = torch.from_numpy(gu.det_labels("iou.lab", (2, 1, 32, 48), 0, 20).astype(np.int64))
+    ev = iouEval(20)
+    ev.addBatch(pred[:1], lab[:1])
+    ev.addBatch(pred[1:], lab[1:])
+    mean, per_class = ev.getIoU()
+    ref = gu.load_json("iou.json")
+    np.testing.assert_allclose(per_class.numpy(), ref["per_class"], rtol=1e-12)
+    assert abs(float(mean) - ref["mean"]) < 1e-12
+    assert ev.tp.dtype == torch.float64 and ev.tp.shape == (19,)
+    assert iouEval(5, ignoreIndex=19).ignoreIndex == -1
+    assert getColorEntry(0.1) == colors.RED and getColorEntry(0.95) == colors.GREEN and getColorEntry("x") == colors.ENDC

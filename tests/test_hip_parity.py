@@ -604,6 +604,35 @@ def test_conv_pair_c_abi_against_torch(C_, N, H, W, axis, d1, d2):
         hipf.conv_pair(x[:, :, :8, :8].contiguous(), packed, ba, bb, axis)
 
 
+def test_iou_eval_gpu_counts():
+    """iouEval.addBatch on GPU label maps (erf_iou_add_batch): the reference's golden IoU, and exact
+    agreement of tp/fp/fn with the one-hot formulation on random maps with and without an ignore
+    class, accumulated over several batches."""
+    from erfnet_pytorch_amd.iouEval import iouEval
+    pred = t(gu.det_labels("iou.pred", (2, 1, 32, 48), 0, 20).astype(np.int64))
+    lab = t(gu.det_labels("iou.lab", (2, 1, 32, 48), 0, 20).astype(np.int64))
+    ev = iouEval(20)
+    n0 = launches()
+    ev.addBatch(pred, lab)
+    assert launches() - n0 == 2
+    mean, per_class = ev.getIoU()
+    ref = gu.load_json("iou.json")
+    np.testing.assert_allclose(per_class.numpy(), ref["per_class"], rtol=1e-12)
+    assert abs(float(mean) - ref["mean"]) < 1e-12
+    g = torch.Generator().manual_seed(11)
+    for ncls, ign in ((20, 19), (7, 19), (2, 1)):
+        a, b = iouEval(ncls, ign), iouEval(ncls, ign)
+        for shape in ((3, 1, 65, 129), (1, 1, 512, 1024)):
+            x = torch.randint(0, ncls, shape, generator=g)
+            y = torch.randint(0, ncls, shape, generator=g)
+            a.addBatch(x.to(DEV), y.to(DEV))
+            b.addBatch(x, y)                       # CPU tensors: one-hot formulation
+        for u, v in ((a.tp, b.tp), (a.fp, b.fp), (a.fn, b.fn)):
+            assert torch.equal(u, v)
+        a.reset()
+        assert float(a.tp.sum()) == 0.0
+
+
 # ------------------------------------------------------------- full benchmark size: properties
 def _torch_nb1d(x, ws, bs, d):
     import torch.nn.functional as F
