@@ -90,6 +90,7 @@ _PROTOS = {
                                          C.c_size_t, vp]),
     "erf_outconv_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, vp]),
+    "erf_outconv_argmax": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "erf_outconv_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_conv2d_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

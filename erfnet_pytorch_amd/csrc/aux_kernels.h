@@ -509,6 +509,56 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
     }
 }
 
+// Class index of the largest logit per output position, written as int64 [N][1][2H][2W]: the
+// `outputs.max(1)[1]` of the evaluation scripts without the logits ever reaching memory.  The
+// logits are formed exactly as in outconv_fwd_kernel (same fma order); ties go to the lowest index.
+__global__ __launch_bounds__(256) void outconv_argmax_kernel(const OutConvDesc d, long long *labels)
+{
+    __shared__ __attribute__((aligned(16))) float ws[OC_MAX_NCLS * 4 * OC_CIN];
+    __shared__ float bs[OC_MAX_NCLS];
+    for (int i = threadIdx.x; i < d.ncls * 4 * OC_CIN; i += 256) {
+        const int c = i % OC_CIN, ab = (i / OC_CIN) % 4, o = i / (OC_CIN * 4);
+        ws[i] = d.w[(c * d.ncls + o) * 4 + ab];
+    }
+    for (int i = threadIdx.x; i < d.ncls; i += 256) bs[i] = d.b ? d.b[i] : 0.0f;
+    __syncthreads();
+    const long long M = (long long)d.N * d.H * d.W;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int n = (int)(m / (d.H * d.W));
+    const int rem = (int)(m - (long long)n * d.H * d.W);
+    const int i = rem / d.W, j = rem - i * d.W;
+    float xv[OC_CIN];
+#pragma unroll
+    for (int q = 0; q < OC_CIN / 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(d.x + m * OC_CIN + q * 4);
+        xv[q * 4] = v[0]; xv[q * 4 + 1] = v[1]; xv[q * 4 + 2] = v[2]; xv[q * 4 + 3] = v[3];
+    }
+    float best[4];
+    int arg[4];
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) { best[ab] = -INFINITY; arg[ab] = 0; }
+    for (int o = 0; o < d.ncls; ++o)
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+            float r = bs[o];
+            const float *w0 = &ws[(o * 4 + ab) * OC_CIN];
+#pragma unroll
+            for (int c = 0; c < OC_CIN; ++c) r = fmaf(xv[c], w0[c], r);
+            // NaN wins like in torch.max; otherwise the first largest value
+            const bool take = r > best[ab] || (r != r && best[ab] == best[ab]);
+            best[ab] = take ? r : best[ab];
+            arg[ab] = take ? o : arg[ab];
+        }
+    const int Ho = 2 * d.H, Wo = 2 * d.W;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        long long *dst = labels + ((long long)n * Ho + 2 * i + a) * Wo + 2 * j;
+        dst[0] = arg[a * 2 + 0];
+        dst[1] = arg[a * 2 + 1];
+    }
+}
+
 // dx[n][i][j][c] = sum_{o,a,b} gy[n][o][2i+a][2j+b] * w[c][o][a][b]   (gy NCHW, dx NHWC)
 struct OutConvBwdDesc {
     const float *x, *w, *gy;

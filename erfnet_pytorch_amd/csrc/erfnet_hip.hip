@@ -1384,6 +1384,21 @@ int erf_outconv_forward(const float *x, const float *w, const float *b, float *y
     return 0;
 }
 
+int erf_outconv_argmax(const float *x, const float *w, const float *b, long long *labels, int N, int Cin,
+                       int H, int W, int ncls, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin != OC_CIN) return fail("output ConvTranspose2d: Cin must be %d (got %d)", OC_CIN, Cin);
+    if (ncls < 1 || ncls > OC_MAX_NCLS) return fail("output ConvTranspose2d: 1 <= classes <= %d", OC_MAX_NCLS);
+    if (!aligned16(x) || !labels) return fail("output ConvTranspose2d: misaligned tensors");
+    const long long M = (long long)N * H * W;
+    if (M == 0) return 0;
+    OutConvDesc d = {x, w, b, nullptr, N, H, W, ncls};
+    outconv_argmax_kernel<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d, labels);
+    CHECK_LAUNCH("outconv_argmax_kernel");
+    return 0;
+}
+
 int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw, float *db,
                          int N, int Cin, int H, int W, int ncls, int flags, void *ws, size_t ws_bytes,
                          void *stream)

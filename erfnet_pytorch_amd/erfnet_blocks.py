@@ -200,6 +200,13 @@ class OutputConvTranspose(nn.ConvTranspose2d):
             return hipf.outconv(input, self.weight, self.bias)
         return super().forward(input, output_size)
 
+    def argmax(self, input):
+        """``self(input).max(1)[1].unsqueeze(1)`` (what eval/eval_iou.py:92 feeds to iouEval); on a
+        GPU one kernel that never writes the logits."""
+        if input.is_cuda:
+            return hipf.outconv_argmax(input, self.weight, self.bias)
+        return super().forward(input).max(1)[1].unsqueeze(1)
+
 
 class SoftMaxConv(nn.Module):
     """convT2x2/2 -> [Dropout2d] -> softmax(dim=1) — reference train/erfnet_blocks.py:92-110."""

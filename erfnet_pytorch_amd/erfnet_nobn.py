@@ -35,9 +35,9 @@ class Decoder(nn.Module):
         self.layers = nn.ModuleList(_nets.eval_decoder_layers(UpsamplerBlock, non_bottleneck_1d))
         self.output_conv = _nets.OutputConvTranspose(16, num_classes)
 
-    def forward(self, input):
+    def forward(self, input, argmax=False):
         input = _nets.run_layers(self.layers, input)
-        return self.output_conv(input)
+        return self.output_conv.argmax(input) if argmax else self.output_conv(input)
 
 
 class ERFNet(nn.Module):
@@ -52,3 +52,8 @@ class ERFNet(nn.Module):
         if only_encode:
             return self.encoder.forward(input, predict=True)
         return self.decoder.forward(self.encoder(input))
+
+    def predict_labels(self, input):
+        """Class index per pixel, int64 [N,1,H,W] — ``self(input).max(1)[1].unsqueeze(1)`` of the
+        evaluation loop (reference eval/eval_iou.py:90-92) without materialising the logits."""
+        return self.decoder.forward(self.encoder(input), argmax=True)

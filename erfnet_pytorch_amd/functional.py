@@ -604,6 +604,20 @@ def outconv_softmax(x, w, b):
     return y
 
 
+def outconv_argmax(x, w, b):
+    """``output_conv(x).max(1)[1].unsqueeze(1)`` (reference eval/eval_iou.py:92) in one kernel,
+    inference only: int64 class indices [N,1,2H,2W]; the logits never reach memory."""
+    lib = _lib.lib()
+    x = _nhwc(x.detach())
+    n, cin, h, wd = x.shape
+    ncls = w.shape[1]
+    wq, bq = _param(w), _param(b)
+    labels = torch.empty((n, 1, 2 * h, 2 * wd), dtype=torch.int64, device=x.device)
+    with _dev_ctx(x):
+        _lib.check(lib.erf_outconv_argmax(_p(x), _p(wq), _p(bq), _p(labels), n, cin, h, wd, ncls, _stream(x)))
+    return labels
+
+
 # ------------------------------------------------------------------------------ plain Conv2d (1x1 / 3x3)
 class _Conv2d(torch.autograd.Function):
     @staticmethod

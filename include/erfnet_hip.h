@@ -163,6 +163,10 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
  * (SoftMaxConv, train/erfnet_blocks.py:104-110). */
 int erf_outconv_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin,
                         int H, int W, int ncls, int softmax, void *stream);
+/* labels[n][0][oh][ow] = argmax over classes of the logits erf_outconv_forward would write: the
+ * `outputs.max(1)[1].unsqueeze(1)` of the scripts (eval/eval_iou.py:92) in one pass, int64, lowest index on ties. */
+int erf_outconv_argmax(const float *x, const float *w, const float *b, long long *labels, int N,
+                       int Cin, int H, int W, int ncls, void *stream);
 /* gy NCHW [N,ncls,2H,2W] = gradient w.r.t. the conv output (pre-softmax); dx NHWC. */
 int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw,
                          float *db, int N, int Cin, int H, int W, int ncls, int flags, void *ws,

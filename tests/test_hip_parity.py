@@ -604,6 +604,21 @@ def test_conv_pair_c_abi_against_torch(C_, N, H, W, axis, d1, d2):
         hipf.conv_pair(x[:, :, :8, :8].contiguous(), packed, ba, bb, axis)
 
 
+def test_predict_labels_equals_argmax_of_logits():
+    """ERFNet.predict_labels (erf_outconv_argmax) against max(1)[1] of the logits of the same
+    network: identical labels, int64 [N,1,H,W]; the CPU path agrees as well."""
+    net = gu.fill_state_dict(make_model("eval_erfnet_nobn_19"), tag="eval_erfnet_nobn_19").eval()
+    x = torch.from_numpy(gu.det_uniform("argmax.x", (2, 3, 64, 96), 0.0, 1.0))
+    with torch.no_grad():
+        lab_cpu = net.predict_labels(x)
+        net = net.to(DEV)
+        logits = first(net(x.to(DEV)))
+        lab = net.predict_labels(x.to(DEV))
+    assert lab.dtype == torch.int64 and lab.shape == (2, 1, 64, 96)
+    assert torch.equal(lab, logits.max(1)[1].unsqueeze(1))
+    assert (lab.cpu() != lab_cpu).float().mean() < 1e-3      # CPU conv rounding may flip near-ties
+
+
 def test_iou_eval_gpu_counts():
     """iouEval.addBatch on GPU label maps (erf_iou_add_batch): the reference's golden IoU, and exact
     agreement of tp/fp/fn with the one-hot formulation on random maps with and without an ignore
