@@ -332,10 +332,16 @@ int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, 
 int run_pair(const PairDesc &pd, int NC, int tile, hipStream_t st)
 {
     if (pd.nlines == 0) return 0;
-    if (NC == 128 && tile == 64) pair_f32_kernel<64, 128><<<pd.nlines, 256, 0, st>>>(pd);
-    else if (NC == 128 && tile == 128) pair_f32_kernel<128, 128><<<pd.nlines, 256, 0, st>>>(pd);
-    else if (NC == 64 && tile == 128) pair_f32_kernel<128, 64><<<pd.nlines, 256, 0, st>>>(pd);
-    else if (NC == 64 && tile == 256) pair_f32_kernel<256, 64><<<pd.nlines, 256, 0, st>>>(pd);
+    // fewer lines than two per CU: eight waves per block halve a block's own latency
+    static int force_nw = -1;
+    if (force_nw < 0) { const char *e = getenv("ERFNET_PAIR_WAVES"); force_nw = e ? atoi(e) : 0; }
+    const bool wide = force_nw == 8 || (force_nw != 4 && pd.nlines <= 512);
+    if (NC == 128 && tile == 64 && wide) pair_f32_kernel<64, 128, 8><<<pd.nlines, 512, 0, st>>>(pd);
+    else if (NC == 64 && tile == 128 && wide) pair_f32_kernel<128, 64, 8><<<pd.nlines, 512, 0, st>>>(pd);
+    else if (NC == 128 && tile == 64) pair_f32_kernel<64, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);
+    else if (NC == 128 && tile == 128) pair_f32_kernel<128, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);
+    else if (NC == 64 && tile == 128) pair_f32_kernel<128, 64, 4><<<pd.nlines, 256, 0, st>>>(pd);
+    else if (NC == 64 && tile == 256) pair_f32_kernel<256, 64, 4><<<pd.nlines, 256, 0, st>>>(pd);
     else return fail("conv pair: no kernel for %d channels, tile %d", NC, tile);
     CHECK_LAUNCH("pair_f32_kernel");
     return 0;

@@ -38,15 +38,17 @@ __device__ __forceinline__ int mid_swz(int row, int chunk)
     return chunk ^ ((row & 7) | ((((row >> 3) ^ (row >> 2)) & 1) << 3));
 }
 
-template <int BM, int NC>
-__global__ __launch_bounds__(256, (BM * NC <= 8192 ? 3 : 2)) void pair_f32_kernel(const PairDesc d)
+// NW = waves per block: 4 for launches that fill the chip (three resident blocks per CU), 8 when
+// there are fewer lines than CU slots (small batches), where a block's own latency sets the time.
+template <int BM, int NC, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2))) void pair_f32_kernel(const PairDesc d)
 {
-    constexpr int KC = 16, CPR = KC / 4, BPITCH = KC + 4, NT = 256, KCH = NC / KC;
-    constexpr int GN = NC / 32, GM = 4 / GN, WM = BM / (32 * GM);
+    constexpr int KC = 16, CPR = KC / 4, BPITCH = KC + 4, NT = NW * 64, KCH = NC / KC;
+    constexpr int GN = NC / 32, GM = NW / GN, WM = BM / (32 * GM);
     static_assert(GM >= 1 && WM >= 1 && GM * WM * 32 == BM, "tile shape");
     constexpr int A_SLOTS = BM * CPR, B_SLOTS = NC * CPR;
-    constexpr int A_PASSES = (A_SLOTS + NT - 1) / NT, B_PASSES = B_SLOTS / NT;
-    static_assert(B_SLOTS % NT == 0 && A_SLOTS % NT == 0, "whole passes");
+    constexpr int A_PASSES = (A_SLOTS + NT - 1) / NT, B_PASSES = (B_SLOTS + NT - 1) / NT;
+    constexpr bool A_FULL = A_SLOTS % NT == 0, B_FULL = B_SLOTS % NT == 0;
     constexpr int NSTEPS = 3 * KCH;
     // mid tile [BM][NC] + one row of zeros (taps of conv_b beyond the line read it); while conv_a
     // runs, its first 2*BM*KC floats are the double-buffered A staging area
@@ -99,19 +101,22 @@ __global__ __launch_bounds__(256, (BM * NC <= 8192 ? 3 : 2)) void pair_f32_kerne
             const int slot = tid + i * NT;
             const int r = slot / CPR, ac = slot % CPR;
             unsigned off = ((tbase + (unsigned)(r * d.pstride)) * NC + kc * KC + ac * 4) * 4u;
-            off |= tapbad | ((unsigned)((L - 1 - r) >> 31) & ERF_OOB);
+            off |= tapbad | ((unsigned)((L - 1 - r) >> 31) & ERF_OOB);      // (covers slots beyond the tile: r >= BM >= L)
             R.a[i] = buf_load4(r_in, off);
         }
         const float *wt = d.wp1 + (long long)(t * KCH + kc) * NC * KC;
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i)
-            R.b[i] = *reinterpret_cast<const f32x4 *>(wt + (tid + i * NT) * 4);
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int slot = tid + i * NT;
+            R.b[i] = *reinterpret_cast<const f32x4 *>(wt + (B_FULL || slot < B_SLOTS ? slot : 0) * 4);
+        }
     };
     auto store_b = [&](int buf, const f32x4 *b) {
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int slot = tid + i * NT;
-            *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = b[i];
+            if (B_FULL || slot < B_SLOTS)
+                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = b[i];
         }
     };
     auto store1 = [&](int buf, const Stage &R) {
@@ -119,7 +124,8 @@ __global__ __launch_bounds__(256, (BM * NC <= 8192 ? 3 : 2)) void pair_f32_kerne
         for (int i = 0; i < A_PASSES; ++i) {
             const int slot = tid + i * NT;
             const int r = slot / CPR, ac = slot % CPR;
-            *reinterpret_cast<f32x4 *>(&Ts[buf * BM * KC + r * KC + ((ac ^ ((r >> 2) & 3)) << 2)]) = R.a[i];
+            if (A_FULL || slot < A_SLOTS)
+                *reinterpret_cast<f32x4 *>(&Ts[buf * BM * KC + r * KC + ((ac ^ ((r >> 2) & 3)) << 2)]) = R.a[i];
         }
         store_b(buf, R.b);
     };
@@ -222,7 +228,10 @@ __global__ __launch_bounds__(256, (BM * NC <= 8192 ? 3 : 2)) void pair_f32_kerne
     auto load_w2 = [&](int s, f32x4 *b) {
         const float *wt = d.wp2 + (long long)s * NC * KC;
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) b[i] = *reinterpret_cast<const f32x4 *>(wt + (tid + i * NT) * 4);
+        for (int i = 0; i < B_PASSES; ++i) {
+            const int slot = tid + i * NT;
+            b[i] = *reinterpret_cast<const f32x4 *>(wt + (B_FULL || slot < B_SLOTS ? slot : 0) * 4);
+        }
     };
     load_w2(0, wb0);
     load_w2(1, wb1);
