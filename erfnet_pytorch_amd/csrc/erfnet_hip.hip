@@ -120,7 +120,7 @@ bool stream16_enabled()
 bool stream16_ok(const IgemmDesc &d)
 {
     if (!stream16_enabled() || !d.vec_ok) return false;
-    if (d.K != 16 || d.Nout != 16 || d.ss != 1 || d.os != 1 || d.ngroups != 1) return false;
+    if (d.K != 16 || d.Nout != 16 || d.ss != 1 || d.os != 1 || d.ngroups != 1 || d.GW < 16) return false;
     if (d.gtap0[0] != 0 || d.gntaps[0] != 3 || d.goa[0] || d.gob[0]) return false;
     if (d.out_C % 4 || d.out_coff % 4 || !aligned16(d.out)) return false;
     if (d.epi.res && (d.epi.res_C % 4 || d.epi.res_coff % 4 || !aligned16(d.epi.res))) return false;

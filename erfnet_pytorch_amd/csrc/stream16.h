@@ -21,7 +21,8 @@
 template <int NTAPS, int U>
 __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
     const unsigned M = (unsigned)d.N * d.GH * d.GW, GHW = (unsigned)d.GH * d.GW;
     const unsigned base = ((unsigned)blockIdx.x * 4 + wave) * (16 * U);
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
     const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 4u);
     const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, (unsigned)d.N * 64u);
     const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
+    const bool has_ns = d.epi.nscale != nullptr, has_mask = d.epi.mask != nullptr, has_res = d.epi.res != nullptr;
 
     float wr[NTAPS][4];
 #pragma unroll
@@ -39,27 +41,45 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
 #pragma unroll
         for (int m = 0; m < 4; ++m) wr[t][m] = d.w[d.woff[t] + (long long)(4 * g + m) * d.wsk + (long long)i * d.wsn];
 
+    // Coordinates: one division pair per wave, on wave-uniform values; the tiles advance by 16
+    // pixels with a uniform wrap, a lane adds its column (GW >= 16: at most one row wrap).
+    unsigned tn = base / GHW;
+    unsigned trem = base - tn * GHW;
+    unsigned tgi = trem / (unsigned)d.GW, tgj = trem - tgi * d.GW;
     f32x4 xv[U][NTAPS], rres[U], rmask[U], rns[U];
     int opix[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const unsigned m = base + u * 16 + i;
         const bool valid = m < M;
-        const unsigned mm = valid ? m : 0;
-        const unsigned n = mm / GHW, rem = mm - n * GHW;
-        const unsigned gi = rem / (unsigned)d.GW, gj = rem - gi * d.GW;
+        unsigned n = tn, gi = tgi, gj = tgj + i;
+        if (gj >= (unsigned)d.GW) {
+            gj -= d.GW;
+            gi += 1;
+            if (gi == (unsigned)d.GH) { gi = 0; n += 1; }
+        }
         const unsigned px = (n * d.out_H + gi) * d.out_W + gj;
         opix[u] = valid ? (int)px : -1;
+        const unsigned vbad = valid ? 0u : ERF_OOB;
 #pragma unroll
         for (int t = 0; t < NTAPS; ++t) {
             const int ih = (int)gi + d.tdh[t], iw = (int)gj + d.tdw[t];
-            const bool ok = valid && (unsigned)ih < (unsigned)d.in_H && (unsigned)iw < (unsigned)d.in_W;
+            const unsigned bad = (unsigned)((ih | iw | (d.in_H - 1 - ih) | (d.in_W - 1 - iw)) >> 31) & ERF_OOB;
             const unsigned off = (((n * d.in_H + ih) * d.in_W + iw) * d.in_C + d.in_coff + 4 * g) * 4u;
-            xv[u][t] = buf_load4(r_in, ok ? off : ERF_OOB);
+            xv[u][t] = buf_load4(r_in, off | bad | vbad);
         }
-        rres[u] = buf_load4(r_res, valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) * 4u : ERF_OOB);
-        rmask[u] = buf_load4(r_mask, valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) * 4u : ERF_OOB);
-        rns[u] = buf_load4(r_ns, (n * 16 + 4 * g) * 4u);
+        rres[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        rmask[u] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        rns[u] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        // absent tensors are skipped with wave-uniform branches (no registers held for them)
+        if (has_res) rres[u] = buf_load4(r_res, ((px * d.epi.res_C + d.epi.res_coff + 4 * g) * 4u) | vbad);
+        if (has_mask) rmask[u] = buf_load4(r_mask, ((px * d.epi.mask_C + d.epi.mask_coff + 4 * g) * 4u) | vbad);
+        if (has_ns) rns[u] = buf_load4(r_ns, (n * 16 + 4 * g) * 4u);
+        tgj += 16;                                   // uniform advance to the next tile
+        while (tgj >= (unsigned)d.GW) {
+            tgj -= d.GW;
+            if (++tgi == (unsigned)d.GH) { tgi = 0; ++tn; }
+        }
     }
     // channel affine of the lane's four output channels 4g..4g+3: v * sc + sh
     f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
@@ -88,7 +108,6 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
             for (int u = 0; u < U; ++u)
                 acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][m], xv[u][t][m], acc[u], 0, 0, 0);
 
-    const bool has_ns = d.epi.nscale != nullptr, has_mask = d.epi.mask != nullptr;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         f32x4 v;
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
             if (has_ns) e *= rns[u][r];
             e += rres[u][r];
             if (d.epi.relu) e = fmaxf(e, 0.0f);
-            v[r] = (!has_mask || rmask[u][r] > 0.0f) ? e : 0.0f;
+            v[r] = rmask[u][r] > 0.0f ? e : 0.0f;
         }
         if (opix[u] >= 0)
             *reinterpret_cast<f32x4 *>(d.out + (unsigned)opix[u] * d.out_C + d.out_coff + 4 * g) = v;
