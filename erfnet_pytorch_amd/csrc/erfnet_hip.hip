@@ -336,7 +336,12 @@ int run_pair(const PairDesc &pd, int NC, int tile, hipStream_t st)
     static int force_nw = -1;
     if (force_nw < 0) { const char *e = getenv("ERFNET_PAIR_WAVES"); force_nw = e ? atoi(e) : 0; }
     const bool wide = force_nw == 8 || (force_nw != 4 && pd.nlines <= 512);
-    if (NC == 128 && tile == 64 && wide) pair_f32_kernel<64, 128, 8><<<pd.nlines, 512, 0, st>>>(pd);
+    // fewer lines than half the CUs: split the second convolution's output channels over two blocks
+    static int no_split = -1;
+    if (no_split < 0) { const char *e = getenv("ERFNET_PAIR_NOSPLIT"); no_split = (e && atoi(e)) ? 1 : 0; }
+    if (NC == 128 && tile == 64 && pd.nlines <= 128 && !no_split && force_nw == 0)
+        pair_f32_kernel<64, 128, 4, 2><<<dim3(pd.nlines, 2, 1), 256, 0, st>>>(pd);
+    else if (NC == 128 && tile == 64 && wide) pair_f32_kernel<64, 128, 8><<<pd.nlines, 512, 0, st>>>(pd);
     else if (NC == 64 && tile == 128 && wide) pair_f32_kernel<128, 64, 8><<<pd.nlines, 512, 0, st>>>(pd);
     else if (NC == 128 && tile == 64) pair_f32_kernel<64, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);
     else if (NC == 128 && tile == 128) pair_f32_kernel<128, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);

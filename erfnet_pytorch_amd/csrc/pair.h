@@ -15,6 +15,7 @@
 // uses — so the results are bit-identical to the two-launch path.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 struct PairDesc {
     const float *in;
@@ -40,9 +41,13 @@ __device__ __forceinline__ int mid_swz(int row, int chunk)
 
 // NW = waves per block: 4 for launches that fill the chip (three resident blocks per CU), 8 when
 // there are fewer lines than CU slots (small batches), where a block's own latency sets the time.
-template <int BM, int NC, int NW>
+// NS = 2 (very small launches): two blocks per line; both run the first convolution in full, each
+// runs the second for one half of the output channels (blockIdx.y), which puts the idle CUs to work.
+template <int BM, int NC, int NW, int NS = 1>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2))) void pair_f32_kernel(const PairDesc d)
 {
+    constexpr int NC2 = NC / NS, GN2 = NC2 / 32, GM2 = NW / GN2, WM2 = BM / (32 * GM2);
+    static_assert(GM2 >= 1 && WM2 >= 1 && GM2 * WM2 * 32 == BM, "tile shape of the second convolution");
     constexpr int KC = 16, CPR = KC / 4, BPITCH = KC + 4, NT = NW * 64, KCH = NC / KC;
     constexpr int GN = NC / 32, GM = NW / GN, WM = BM / (32 * GM);
     static_assert(GM >= 1 && WM >= 1 && GM * WM * 32 == BM, "tile shape");
@@ -69,12 +74,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
 
     for (int i = tid; i < NC; i += NT) Ts[BM * NC + i] = 0.0f;
 
-    // per-column constants of both epilogues
+    // per-column constants of both epilogues (the second convolution has its own wave layout when
+    // the output channels are split over two blocks)
     const int col = wn * 32 + l31;
+    const int wm2 = wave / GN2, wn2 = wave % GN2;
+    const int colb = wn2 * 32 + l31;                         // column within the block's B tile
+    const int col2 = (NS > 1 ? (int)blockIdx.y * NC2 : 0) + colb;
     float sc1, sh1, sc2, sh2;
     epi_channel_affine(d.epi1, col, sc1, sh1);
-    epi_channel_affine(d.epi2, col, sc2, sh2);
+    epi_channel_affine(d.epi2, col2, sc2, sh2);
 
+    static_assert(WM2 <= WM, "accumulators are shared");
     f32x16 acc[WM];
     auto clear_acc = [&]() {
 #pragma unroll
@@ -169,18 +179,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
     // All loads of an epilogue (residual, mask) are issued before the first store: the compiler
     // must assume that a store may alias a later load, so interleaving them would expose one
     // memory latency per group of rows.  Absent tensors are skipped with wave-uniform branches.
-    auto epilogue = [&](const Epilogue &e, float sc, float sh, float *dst, bool to_lds) {
+    auto epilogue = [&](const Epilogue &e, float sc, float sh, float *dst, bool to_lds, auto wtag, int wmx, int col) {
+        constexpr int WMX = decltype(wtag)::value;
         const __amdgpu_buffer_rsrc_t r_out = make_rsrc(dst, P * NC * 4u);
         const __amdgpu_buffer_rsrc_t r_res = make_rsrc(e.res, P * e.res_C * 4u);
         const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(e.mask, P * e.mask_C * 4u);
         const bool has_mask = e.mask != nullptr, has_res = e.res != nullptr, relu = e.relu != 0;
         // row of accumulator element r: a wave-uniform part (scalar offset operand of the buffer
         // instructions) plus 4 * (lane >> 5) (part of the per-lane offset)
-        auto urow = [&](int a, int r) { return (wm * WM + a) * 32 + (r & 3) + 8 * (r >> 2); };
+        auto urow = [&](int a, int r) { return (wmx * WMX + a) * 32 + (r & 3) + 8 * (r >> 2); };
         const unsigned px0 = base + (unsigned)(4 * h * d.pstride);
-        float rres[WM][16], rmask[WM][16];
+        float rres[WMX][16], rmask[WMX][16];
 #pragma unroll
-        for (int a = 0; a < WM; ++a)
+        for (int a = 0; a < WMX; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { rres[a][r] = 0.0f; rmask[a][r] = 1.0f; }
         // rows beyond the line need no guard on the load side: the value is not used, and an
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
             const unsigned voff = (px0 * e.res_C + e.res_coff + col) * 4u;
             const unsigned rowb = (unsigned)(d.pstride * e.res_C) * 4u;
 #pragma unroll
-            for (int a = 0; a < WM; ++a)
+            for (int a = 0; a < WMX; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     rres[a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
             const unsigned voff = (px0 * e.mask_C + e.mask_coff + col) * 4u;
             const unsigned rowb = (unsigned)(d.pstride * e.mask_C) * 4u;
 #pragma unroll
-            for (int a = 0; a < WM; ++a)
+            for (int a = 0; a < WMX; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     rmask[a][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
         const unsigned ovoff = (px0 * NC + col) * 4u;
         const unsigned orowb = (unsigned)(d.pstride * NC) * 4u;
 #pragma unroll
-        for (int a = 0; a < WM; ++a)
+        for (int a = 0; a < WMX; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rw = urow(a, r) + 4 * h;
@@ -224,21 +235,32 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
     };
 
     // conv_b's first two weight tiles travel while the first epilogue runs
-    f32x4 wb0[B_PASSES], wb1[B_PASSES];
+    constexpr int B_SLOTS2 = NC2 * CPR, B_PASSES2 = (B_SLOTS2 + NT - 1) / NT;
+    constexpr bool B_FULL2 = B_SLOTS2 % NT == 0;
+    f32x4 wb0[B_PASSES2], wb1[B_PASSES2];
     auto load_w2 = [&](int s, f32x4 *b) {
-        const float *wt = d.wp2 + (long long)s * NC * KC;
+        const float *wt = d.wp2 + (long long)s * NC * KC + (NS > 1 ? (int)blockIdx.y * NC2 * KC : 0);
 #pragma unroll
-        for (int i = 0; i < B_PASSES; ++i) {
+        for (int i = 0; i < B_PASSES2; ++i) {
             const int slot = tid + i * NT;
-            b[i] = *reinterpret_cast<const f32x4 *>(wt + (B_FULL || slot < B_SLOTS ? slot : 0) * 4);
+            b[i] = *reinterpret_cast<const f32x4 *>(wt + (B_FULL2 || slot < B_SLOTS2 ? slot : 0) * 4);
+        }
+    };
+    auto store_b2 = [&](int buf, const f32x4 *b) {
+#pragma unroll
+        for (int i = 0; i < B_PASSES2; ++i) {
+            const int slot = tid + i * NT;
+            if (B_FULL2 || slot < B_SLOTS2)
+                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = b[i];
         }
     };
     load_w2(0, wb0);
     load_w2(1, wb1);
-    epilogue(d.epi1, sc1, sh1, d.mid, true);
-    store_b(0, wb0);
+    epilogue(d.epi1, sc1, sh1, (NS > 1 && blockIdx.y != 0) ? nullptr : d.mid, true,
+             std::integral_constant<int, WM>{}, wm, col);
+    store_b2(0, wb0);
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) wb0[i] = wb1[i];
+    for (int i = 0; i < B_PASSES2; ++i) wb0[i] = wb1[i];
     clear_acc();
     __syncthreads();
 
@@ -246,34 +268,34 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
 #pragma unroll 2
     for (int s = 0; s < NSTEPS; ++s) {
         const int buf = s & 1;
-        if (s + 1 < NSTEPS) store_b(buf ^ 1, wb0);
+        if (s + 1 < NSTEPS) store_b2(buf ^ 1, wb0);
         if (s + 2 < NSTEPS) load_w2(s + 2, wb0);
         const int t = s / KCH, kc = s % KCH;
         const int sh = t == 0 ? s2a : (t == 1 ? s2b : s2c);
         const float *Bb = Bs[buf];
-        const float *arow[WM];
-        int asw[WM];
+        const float *arow[WM2];
+        int asw[WM2];
 #pragma unroll
-        for (int a = 0; a < WM; ++a) {
-            const int rr = (wm * WM + a) * 32 + l31 + sh;
+        for (int a = 0; a < WM2; ++a) {
+            const int rr = (wm2 * WM2 + a) * 32 + l31 + sh;
             const int rz = (unsigned)rr < (unsigned)L ? rr : BM;       // beyond the line: the zero row
             arow[a] = Ts + rz * NC;
             asw[a] = (rz & 7) | ((((rz >> 3) ^ (rz >> 2)) & 1) << 3);
         }
 #pragma unroll
         for (int qq = 0; qq < KC / 8; ++qq) {
-            f32x4 af[WM], bf;
+            f32x4 af[WM2], bf;
 #pragma unroll
-            for (int a = 0; a < WM; ++a)
+            for (int a = 0; a < WM2; ++a)
                 af[a] = *reinterpret_cast<const f32x4 *>(arow[a] + (((kc * CPR + 2 * qq + h) ^ asw[a]) << 2));
-            bf = *reinterpret_cast<const f32x4 *>(&Bb[col * BPITCH + qq * 8 + h * 4]);
+            bf = *reinterpret_cast<const f32x4 *>(&Bb[colb * BPITCH + qq * 8 + h * 4]);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int a = 0; a < WM; ++a)
+                for (int a = 0; a < WM2; ++a)
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[m], acc[a], 0, 0, 0);
         }
         __syncthreads();
     }
-    epilogue(d.epi2, sc2, sh2, d.out, false);
+    epilogue(d.epi2, sc2, sh2, d.out, false, std::integral_constant<int, WM2>{}, wm2, col2);
 }
