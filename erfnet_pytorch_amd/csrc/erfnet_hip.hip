@@ -182,20 +182,23 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
 
 int launch_pack(const PackDesc *pks, int n, hipStream_t st)
 {
-    PackBatch b;
-    memset(&b, 0, sizeof(b));
-    size_t most = 0;
-    for (int i = 0; i < n; ++i) {
-        b.p[i] = pks[i];
-        if (!pks[i].kc) continue;          // convolution that reads torch's layout directly
-        const size_t tot = (size_t)pks[i].ntaps * ((pks[i].K + pks[i].kc - 1) / pks[i].kc) * pks[i].Npad * pks[i].kc;
-        most = tot > most ? tot : most;
+    for (int first = 0; first < n; first += ERF_PACK_BATCH) {
+        const int cnt = n - first < ERF_PACK_BATCH ? n - first : ERF_PACK_BATCH;
+        PackBatch b;
+        memset(&b, 0, sizeof(b));
+        size_t most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            b.p[i] = pks[first + i];
+            if (!b.p[i].kc) continue;          // convolution that reads torch's layout directly
+            const size_t tot = (size_t)b.p[i].ntaps * ((b.p[i].K + b.p[i].kc - 1) / b.p[i].kc) * b.p[i].Npad * b.p[i].kc;
+            most = tot > most ? tot : most;
+        }
+        if (most == 0) continue;
+        dim3 grid((unsigned)((most + 255) / 256), cnt, 1);
+        if (grid.x > 512) grid.x = 512;
+        pack_weights_kernel<<<grid, 256, 0, st>>>(b);
+        CHECK_LAUNCH("pack_weights_kernel");
     }
-    if (most == 0) return 0;
-    dim3 grid((unsigned)((most + 255) / 256), n, 1);
-    if (grid.x > 512) grid.x = 512;
-    pack_weights_kernel<<<grid, 256, 0, st>>>(b);
-    CHECK_LAUNCH("pack_weights_kernel");
     return 0;
 }
 
@@ -1062,8 +1065,7 @@ int nb1d_chain_segment(const float *x, const erf_nb1d_block_t *blk, int nb, int 
             k[4] = two[1];          // slot 0 of the next block
         } else if (plan_igemm(P.d[3], ar, k[3])) return 1;
     }
-    for (int i = 0; i < nb; i += 1)
-        if (launch_pack(pk + 4 * i, 4, st)) return 1;      // one launch repacks a block's weight tensors
+    if (launch_pack(pk, 4 * nb, st)) return 1;             // one launch repacks the weights of the whole run
 
     for (int i = 0; i < nb; ++i) {
         const erf_nb1d_block_t &B = blk[i];

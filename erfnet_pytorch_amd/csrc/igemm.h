@@ -33,15 +33,16 @@ __device__ __forceinline__ int a_swz(int row, int chunk)
 // Weights are repacked once per call from torch's layout into the order the B tile is consumed:
 //   wp[tap][k-chunk][j][KC]  (k = contraction channel, j = output channel, zero padded to Npad
 //   columns and to whole KC-channel chunks), so a K-step's B tile is one contiguous run that is
-//   copied with 16-byte loads.  Up to four convolutions (one non_bottleneck_1d) per launch.
+//   copied with 16-byte loads.  Up to 32 convolutions (a chain of eight non_bottleneck_1d) per launch.
 struct PackDesc {
     const float *w;
     float *wp;
     int ntaps, K, Nout, Npad, wsk, wsn, kc;    // kc = channels per K-step (16 or 32)
     int woff[ERF_MAX_TAPS];
 };
+#define ERF_PACK_BATCH 32
 struct PackBatch {
-    PackDesc p[4];
+    PackDesc p[ERF_PACK_BATCH];
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackBatch b)
