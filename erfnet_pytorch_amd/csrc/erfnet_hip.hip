@@ -207,7 +207,14 @@ int run_igemm(const IgemmDesc &d, hipStream_t st)
     const long long M = (long long)d.N * d.GH * d.GW;
     if (M == 0) return 0;
     if (d.cfg == kCfgStream16) {
-        conv16_kernel<3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
+        // tile groups per wave: the per-wave set-up (descriptors, weights, coordinates) is paid once,
+        // as long as about 12 waves per CU remain (ERFNET_CONV16_G overrides, experiments)
+        static int forced = -1;
+        if (forced < 0) { const char *e = getenv("ERFNET_CONV16_G"); forced = e ? atoi(e) : 0; }
+        const int grp = forced ? forced : (M >= 3072LL * 256 ? 4 : (M >= 3072LL * 128 ? 2 : 1));
+        if (grp >= 4) conv16_kernel<3, 4, 4><<<(unsigned)((M + 1023) / 1024), 256, 0, st>>>(d);
+        else if (grp >= 2) conv16_kernel<3, 4, 2><<<(unsigned)((M + 511) / 512), 256, 0, st>>>(d);
+        else conv16_kernel<3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
         CHECK_LAUNCH("conv16_kernel");
         return 0;
     }

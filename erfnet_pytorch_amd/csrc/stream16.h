@@ -18,15 +18,15 @@
 // A lane loads channels 4g..4g+3 of pixel i; MFMA number m of a tap takes element m, i.e. the
 // instruction's k index g stands for channel 4g + m, and the weight operand uses the same map.
 // One wave = U tiles of 16 consecutive pixels (independent accumulators hide the MFMA latency).
-template <int NTAPS, int U>
+template <int NTAPS, int U, int G = 1>
 __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, g = lane >> 4;
     const unsigned M = (unsigned)d.N * d.GH * d.GW, GHW = (unsigned)d.GH * d.GW;
-    const unsigned base = ((unsigned)blockIdx.x * 4 + wave) * (16 * U);
-    if (base >= M) return;
+    const unsigned base0 = ((unsigned)blockIdx.x * 4 + wave) * (16 * U * G);
+    if (base0 >= M) return;
     const unsigned Pin = (unsigned)d.N * d.in_H * d.in_W, Pout = (unsigned)d.N * d.out_H * d.out_W;
     const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, Pin * d.in_C * 4u);
     const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * 4u);
@@ -43,9 +43,28 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
 
     // Coordinates: one division pair per wave, on wave-uniform values; the tiles advance by 16
     // pixels with a uniform wrap, a lane adds its column (GW >= 16: at most one row wrap).
-    unsigned tn = base / GHW;
-    unsigned trem = base - tn * GHW;
+    unsigned tn = base0 / GHW;
+    unsigned trem = base0 - tn * GHW;
     unsigned tgi = trem / (unsigned)d.GW, tgj = trem - tgi * d.GW;
+    // channel affine of the lane's four output channels 4g..4g+3: v * sc + sh
+    f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    f32x4 sh = buf_load4(r_bias, g * 16u);
+    if (d.epi.bn.on) {          // wave-uniform
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(d.epi.bn.gamma + 4 * g);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(d.epi.bn.beta + 4 * g);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(d.epi.bn.mean + 4 * g);
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(d.epi.bn.var + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = d.epi.bn.var_is_invstd ? va[r] : rsqrtf(va[r] + d.epi.bn.eps);
+            sc[r] = ga[r] * inv;
+            sh[r] = (sh[r] - mu[r]) * sc[r] + be[r];
+        }
+    }
+
+    for (int grp = 0; grp < G; ++grp) {
+    const unsigned base = base0 + grp * (16 * U);
+    if (base >= M) break;
     f32x4 xv[U][NTAPS], rres[U], rmask[U], rns[U];
     int opix[U];
 #pragma unroll
@@ -81,22 +100,6 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
             if (++tgi == (unsigned)d.GH) { tgi = 0; ++tn; }
         }
     }
-    // channel affine of the lane's four output channels 4g..4g+3: v * sc + sh
-    f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
-    f32x4 sh = buf_load4(r_bias, g * 16u);
-    if (d.epi.bn.on) {          // wave-uniform
-        const f32x4 ga = *reinterpret_cast<const f32x4 *>(d.epi.bn.gamma + 4 * g);
-        const f32x4 be = *reinterpret_cast<const f32x4 *>(d.epi.bn.beta + 4 * g);
-        const f32x4 mu = *reinterpret_cast<const f32x4 *>(d.epi.bn.mean + 4 * g);
-        const f32x4 va = *reinterpret_cast<const f32x4 *>(d.epi.bn.var + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float inv = d.epi.bn.var_is_invstd ? va[r] : rsqrtf(va[r] + d.epi.bn.eps);
-            sc[r] = ga[r] * inv;
-            sh[r] = (sh[r] - mu[r]) * sc[r] + be[r];
-        }
-    }
-
     f32x4 acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
         }
         if (opix[u] >= 0)
             *reinterpret_cast<f32x4 *>(d.out + (unsigned)opix[u] * d.out_C + d.out_coff + 4 * g) = v;
+    }
     }
 }
 
