@@ -443,8 +443,8 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
     for (int i = threadIdx.x; i < d.ncls; i += 256) bs[i] = d.b ? d.b[i] : 0.0f;
     __syncthreads();
     const long long M = (long long)d.N * d.H * d.W;
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
+    // grid-stride over the input pixels: the weight tile in LDS is filled once per block
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
     const int n = (int)(m / (d.H * d.W));
     const int rem = (int)(m - (long long)n * d.H * d.W);
     const int i = rem / d.W, j = rem - i * d.W;
@@ -507,6 +507,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
                 *reinterpret_cast<f32x2 *>(d.y + (((long long)n * d.ncls + o) * Ho + 2 * i + a) * Wo + 2 * j) = st;
             }
     }
+    }
 }
 
 // Class index of the largest logit per output position, written as int64 [N][1][2H][2W]: the
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(256) void outconv_argmax_kernel(const OutConvDesc d
     for (int i = threadIdx.x; i < d.ncls; i += 256) bs[i] = d.b ? d.b[i] : 0.0f;
     __syncthreads();
     const long long M = (long long)d.N * d.H * d.W;
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
+    // grid-stride over the input pixels: the weight tile in LDS is filled once per block
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
     const int n = (int)(m / (d.H * d.W));
     const int rem = (int)(m - (long long)n * d.H * d.W);
     const int i = rem / d.W, j = rem - i * d.W;
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(256) void outconv_argmax_kernel(const OutConvDesc d
         dst[0] = arg[a * 2 + 0];
         dst[1] = arg[a * 2 + 1];
     }
+    }
 }
 
 // dx[n][i][j][c] = sum_{o,a,b} gy[n][o][2i+a][2j+b] * w[c][o][a][b]   (gy NCHW, dx NHWC)
@@ -576,8 +578,8 @@ __global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc
     }
     __syncthreads();
     const long long M = (long long)d.N * d.H * d.W;
-    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
+    // grid-stride over the input pixels: the weight tile in LDS is filled once per block
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
     const int n = (int)(m / (d.H * d.W));
     const int rem = (int)(m - (long long)n * d.H * d.W);
     const int i = rem / d.W, j = rem - i * d.W;
@@ -604,6 +606,7 @@ __global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc
             for (int e = 0; e < 4; ++e) v[e] = xv[e] > 0.0f ? v[e] : 0.0f;
         }
         *reinterpret_cast<f32x4 *>(d.dx + m * OC_CIN + q * 4) = v;
+    }
     }
 }
 

@@ -1389,6 +1389,14 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
 }
 
 // ================================================================================ output conv
+// Blocks of the output-convolution kernels: they stride over the pixels, so a block fills its LDS
+// weight tile once; about four resident blocks per CU.
+static unsigned outconv_grid(long long M)
+{
+    const long long b = (M + 255) / 256;
+    return (unsigned)(b < 1024 ? (b < 1 ? 1 : b) : 1024);
+}
+
 int erf_outconv_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin, int H,
                         int W, int ncls, int softmax, void *stream)
 {
@@ -1398,8 +1406,8 @@ int erf_outconv_forward(const float *x, const float *w, const float *b, float *y
     if (!aligned16(x) || ((uintptr_t)y & 7)) return fail("output ConvTranspose2d: misaligned tensors");
     const long long M = (long long)N * H * W;
     OutConvDesc d = {x, w, b, y, N, H, W, ncls};
-    if (softmax) outconv_fwd_kernel<true><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
-    else outconv_fwd_kernel<false><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
+    if (softmax) outconv_fwd_kernel<true><<<outconv_grid(M), 256, 0, st>>>(d);
+    else outconv_fwd_kernel<false><<<outconv_grid(M), 256, 0, st>>>(d);
     CHECK_LAUNCH("outconv_fwd_kernel");
     return 0;
 }
@@ -1414,7 +1422,7 @@ int erf_outconv_argmax(const float *x, const float *w, const float *b, long long
     const long long M = (long long)N * H * W;
     if (M == 0) return 0;
     OutConvDesc d = {x, w, b, nullptr, N, H, W, ncls};
-    outconv_argmax_kernel<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d, labels);
+    outconv_argmax_kernel<<<outconv_grid(M), 256, 0, st>>>(d, labels);
     CHECK_LAUNCH("outconv_argmax_kernel");
     return 0;
 }
@@ -1440,7 +1448,7 @@ int erf_outconv_backward(const float *x, const float *w, const float *gy, float 
     if (!partial) return fail("output ConvTranspose2d backward: workspace too small");
     OutConvBwdDesc d = {x, w, gy, dx, partial, N, H, W, ncls, (int)sp, (flags & ERF_BWD_MASK_DX) ? 1 : 0};
     if (dx) {
-        outconv_dgrad_kernel<<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
+        outconv_dgrad_kernel<<<outconv_grid(M), 256, 0, st>>>(d);
         CHECK_LAUNCH("outconv_dgrad_kernel");
     }
     outconv_wgrad_kernel<<<(unsigned)nsplit, 256, 0, st>>>(d);
