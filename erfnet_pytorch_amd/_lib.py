@@ -105,7 +105,7 @@ _PROTOS = {
 }
 
 BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
-OPT_PAIR_FUSION = 1
+OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16 = 1, 2, 3
 
 EXPORTS = tuple(_PROTOS)
 

@@ -21,6 +21,31 @@ namespace {
 thread_local char g_err[512] = "";
 std::atomic<unsigned long long> g_launches{0};
 
+// Kernel-path switches: -1 = not read yet (the environment variable decides), else 0 / 1.
+// erf_set_option overrides them at run time (A/B tests in one process).
+struct Switch {
+    std::atomic<int> v{-1};
+    const char *off_env;
+    explicit Switch(const char *env) : off_env(env) {}
+    bool on()
+    {
+        int x = v.load(std::memory_order_relaxed);
+        if (x < 0) {
+            const char *e = getenv(off_env);
+            x = (e && atoi(e)) ? 0 : 1;
+            v.store(x, std::memory_order_relaxed);
+        }
+        return x != 0;
+    }
+    int set(int value)
+    {
+        const int prev = on() ? 1 : 0;
+        v.store(value ? 1 : 0, std::memory_order_relaxed);
+        return prev;
+    }
+};
+Switch g_sw_pair("ERFNET_NO_PAIR"), g_sw_wgrad_line("ERFNET_NO_WGRAD_LINE"), g_sw_stream16("ERFNET_NO_STREAM16");
+
 int fail(const char *fmt, ...)
 {
     va_list ap;
@@ -111,12 +136,7 @@ int pick_cfg(long long M, int first, int count)
 // whose tensors allow 16-byte accesses and 32-bit element offsets.  ERFNET_NO_STREAM16=1 turns the
 // path off (experiments).
 const int kCfgStream16 = 100;
-bool stream16_enabled()
-{
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("ERFNET_NO_STREAM16"); on = (e && atoi(e)) ? 0 : 1; }
-    return on != 0;
-}
+bool stream16_enabled() { return g_sw_stream16.on(); }
 bool stream16_ok(const IgemmDesc &d)
 {
     if (!stream16_enabled() || !d.vec_ok) return false;
@@ -252,17 +272,7 @@ int launch_igemm(IgemmDesc &d, Arena &ar, hipStream_t st)
 // Two consecutive 1-D convolutions of a non_bottleneck_1d (the first across the lines the second
 // runs along) go into one launch of pair_f32_kernel when the line fits a block tile.
 // ERFNET_NO_PAIR=1 keeps every convolution in a launch of its own (experiments, A/B tests).
-std::atomic<int> g_pair_on{-1};
-bool pair_enabled()
-{
-    int on = g_pair_on.load(std::memory_order_relaxed);
-    if (on < 0) {
-        const char *e = getenv("ERFNET_NO_PAIR");
-        on = (e && atoi(e)) ? 0 : 1;
-        g_pair_on.store(on, std::memory_order_relaxed);
-    }
-    return on != 0;
-}
+bool pair_enabled() { return g_sw_pair.on(); }
 
 // Tile variant (block pixels) for a line of L pixels and NC channels, 0 = none.
 int pair_tile(int NC, int L)
@@ -273,9 +283,9 @@ int pair_tile(int NC, int L)
 }
 
 // a = first convolution, b = second (b.in is a.out).  Returns the tile variant or 0.
-int pair_variant(const IgemmDesc &a, const IgemmDesc &b)
+int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = false)
 {
-    if (!pair_enabled()) return 0;
+    if (!ignore_switch && !pair_enabled()) return 0;
     const int NC = a.K;
     const IgemmDesc *dd[2] = {&a, &b};
     for (const IgemmDesc *d : dd) {
@@ -390,9 +400,7 @@ int launch_reduce_batch(const WgradDesc *d, int n, float *const *dw, float *cons
 // G read once).  ERFNET_NO_WGRAD_LINE=1 keeps them on wgrad_f32_kernel (experiments).
 bool wgrad_line_ok(const WgradDesc *dd, int n)
 {
-    static int on = -1;
-    if (on < 0) { const char *e = getenv("ERFNET_NO_WGRAD_LINE"); on = (e && atoi(e)) ? 0 : 1; }
-    if (!on) return false;
+    if (!g_sw_wgrad_line.on()) return false;
     const int NC = dd[0].K;
     if (NC != 64 && NC != 128) return false;
     for (int i = 0; i < n; ++i) {
@@ -808,11 +816,9 @@ int erf_version(void) { return 100; }
 
 int erf_set_option(int option, int value)
 {
-    if (option == ERF_OPT_PAIR_FUSION) {
-        const int prev = pair_enabled() ? 1 : 0;
-        g_pair_on.store(value ? 1 : 0, std::memory_order_relaxed);
-        return prev;
-    }
+    if (option == ERF_OPT_PAIR_FUSION) return g_sw_pair.set(value);
+    if (option == ERF_OPT_WGRAD_LINE) return g_sw_wgrad_line.set(value);
+    if (option == ERF_OPT_STREAM16) return g_sw_stream16.set(value);
     return -1;
 }
 const char *erf_last_error(void) { return g_err; }
@@ -1176,10 +1182,7 @@ int erf_conv_pair_forward(const float *x, const float *packed, const float *b_fi
     a.epi.bias = b_first; a.epi.relu = relu_first ? 1 : 0;
     b.epi.bias = b_second; b.epi.relu = relu_second ? 1 : 0;
     if (residual) { b.epi.res = residual; b.epi.res_C = C; }
-    const int saved = g_pair_on.load(std::memory_order_relaxed);
-    g_pair_on.store(1, std::memory_order_relaxed);
-    const int tile = pair_variant(a, b);
-    g_pair_on.store(saved, std::memory_order_relaxed);
+    const int tile = pair_variant(a, b, true);
     if (!tile) return fail("conv pair: %d channels with lines of %d pixels have no fused kernel", C, first_axis ? H : W);
     PairDesc pd;
     memset(&pd, 0, sizeof(pd));

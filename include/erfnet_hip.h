@@ -55,6 +55,12 @@ unsigned long long erf_launch_count(void);
  * it off): consecutive 1-D convolutions of a non_bottleneck_1d run as one launch where the image
  * geometry allows; results are bit-identical either way. */
 #define ERF_OPT_PAIR_FUSION 1
+/* ERF_OPT_WGRAD_LINE (default 1; ERFNET_NO_WGRAD_LINE=1): weight gradients of the 64/128-channel
+ * 1-D convolutions with all three taps per block; off = one block per tap.  ERF_OPT_STREAM16
+ * (default 1; ERFNET_NO_STREAM16=1): LDS-free kernels for the 16-channel layers; off = the general
+ * implicit-GEMM kernels.  Either way the results agree to fp32 rounding (different summation order). */
+#define ERF_OPT_WGRAD_LINE 2
+#define ERF_OPT_STREAM16 3
 int erf_set_option(int option, int value);
 
 /* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block

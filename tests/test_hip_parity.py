@@ -604,6 +604,45 @@ def test_conv_pair_c_abi_against_torch(C_, N, H, W, axis, d1, d2):
         hipf.conv_pair(x[:, :, :8, :8].contiguous(), packed, ba, bb, axis)
 
 
+@pytest.mark.parametrize("C_,d,N,H,W", [(128, 4, 2, 64, 40), (128, 1, 1, 24, 130), (64, 1, 2, 128, 36),
+                                        (64, 2, 1, 70, 200), (16, 1, 2, 40, 48)])
+def test_alternative_kernel_paths_agree(C_, d, N, H, W):
+    """The specialised kernels (line weight gradients for 64/128 channels, LDS-free kernels for 16
+    channels) against the general implicit-GEMM / per-tap kernels on the same block: outputs equal
+    bit for bit where only the launch plan differs, gradients to fp32 rounding of the sum
+    (different summation order over ~10^4..10^5 pixels)."""
+    from erfnet_pytorch_amd import functional as hipf, _lib
+    g = torch.Generator(device="cpu").manual_seed(3 * C_ + H)
+    x = torch.randn(N, C_, H, W, generator=g).clamp_(min=0).to(DEV).contiguous(memory_format=torch.channels_last)
+    ws = [(torch.randn(C_, C_, *k, generator=g) * (0.6 / C_ ** 0.5)).to(DEV).requires_grad_(True)
+          for k in ((3, 1), (1, 3), (3, 1), (1, 3))]
+    bs = [(torch.randn(C_, generator=g) * 0.1).to(DEV).requires_grad_(True) for _ in range(4)]
+    gy = torch.randn(N, C_, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        for q in ws + bs:
+            q.grad = None
+        xx = x.clone().requires_grad_(True)
+        y = hipf.nb1d(xx, ws, bs, d)
+        y.backward(gy)
+        return [y.detach(), xx.grad] + [q.grad.clone() for q in ws + bs]
+
+    opts = (_lib.OPT_WGRAD_LINE, _lib.OPT_STREAM16)
+    prev = [_lib.set_option(o, 1) for o in opts]
+    try:
+        fast = run()
+        for o in opts:
+            _lib.set_option(o, 0)
+        plain = run()
+    finally:
+        for o, v in zip(opts, prev):
+            _lib.set_option(o, v)
+    if C_ != 16:
+        assert torch.equal(fast[0], plain[0]) and torch.equal(fast[1], plain[1])
+    for i, (u, v) in enumerate(zip(fast, plain)):
+        gu.check_arrays(u.cpu().numpy(), v.cpu().numpy(), 1e-5, 1e-4, what=f"tensor{i}", scale_rtol=2e-5)
+
+
 def test_predict_labels_equals_argmax_of_logits():
     """ERFNet.predict_labels (erf_outconv_argmax) against max(1)[1] of the logits of the same
     network: identical labels, int64 [N,1,H,W]; the CPU path agrees as well."""
