@@ -106,12 +106,18 @@ class non_bottleneck_1d(nn.Module):
 
     def _gpu_args(self, input):
         """Keyword arguments of functional.nb1d for this block (draws the dropout mask)."""
-        convs = [getattr(self, n) for n in self._CONVS]
+        mods = self._modules            # direct look-ups: this runs once per block per forward
+        convs = [mods[n] for n in self._CONVS]
         mode = _bn_mode(self, self.use_batchnorm)
-        scale = _dropout2d_scale(input, self.dropout.p, self._dropout_enabled() and self.training)
-        return dict(weights=[c.weight for c in convs], biases=[c.bias for c in convs],
-                    dilated=self.dilated, bn1=_bn_args(self.bn1), bn2=_bn_args(self.bn2), bn_mode=mode,
-                    drop_scale=scale, momentum=self.bn1.momentum, eps=self.bn1.eps)
+        scale = None
+        if self.use_dropout and self.training:
+            scale = _dropout2d_scale(input, mods["dropout"].p, self._dropout_enabled())
+        kw = dict(weights=[c._parameters["weight"] for c in convs], biases=[c._parameters["bias"] for c in convs],
+                  dilated=self.dilated, bn_mode=mode, drop_scale=scale)
+        if mode:
+            bn1, bn2 = mods["bn1"], mods["bn2"]
+            kw.update(bn1=_bn_args(bn1), bn2=_bn_args(bn2), momentum=bn1.momentum, eps=bn1.eps)
+        return kw
 
     def forward(self, input):
         if input.is_cuda:

@@ -68,6 +68,13 @@ def _param(t):
     return t.detach().contiguous()
 
 
+def _plain(t):
+    """A parameter whose memory is handed to the library as it is (fp32, dense)."""
+    if t.dtype != torch.float32:
+        raise TypeError("parameters must be fp32")
+    return t if t.is_contiguous() else t.detach().contiguous()
+
+
 class _Bn:
     """Per-call BatchNorm state handed to the library (mode 0 = off, 1 = eval, 2 = train)."""
 
@@ -91,8 +98,39 @@ class _Bn:
         return C.byref(self.struct) if self.mode else None
 
 
+class _NoBn:
+    """Stand-in for an absent BatchNorm (mode 0)."""
+    mode = 0
+    gamma = beta = save_mean = save_invstd = None
+
+    @staticmethod
+    def ref():
+        return None
+
+
+_NO_BN = _NoBn()
+
+
 def _arr(ts):
     return (vp * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+
+
+class _InferenceCtx:
+    """Minimal stand-in for an autograd context: under torch.no_grad() the block functions are called
+    directly, which skips the autograd machinery of Function.apply (tens of microseconds per call,
+    a third of the host time of a batch-1 forward)."""
+
+    def __init__(self, n_inputs):
+        self.needs_input_grad = (False,) * n_inputs
+
+    def save_for_backward(self, *tensors):
+        pass
+
+
+def _apply(fn, *args):
+    if torch.is_grad_enabled():
+        return fn.apply(*args)
+    return fn.forward(_InferenceCtx(len(args)), *args)
 
 
 # ReLU-mask hand-over between neighbouring blocks.  Every block output is a ReLU output, and the
@@ -239,7 +277,7 @@ def downsampler(x, w, b, bn_weight=None, bn_bias=None, running_mean=None, runnin
                 bn_mode=0, momentum=0.1, eps=1e-3):
     """DownsamplerBlock.forward of the reference (train/erfnet_blocks.py:25-29) on the GPU."""
     tok = _ReluToken()
-    return _tag_output(_Downsampler.apply(x, w, b, bn_weight if bn_mode else None,
+    return _tag_output(_apply(_Downsampler, x, w, b, bn_weight if bn_mode else None,
                                           bn_bias if bn_mode else None, running_mean, running_var,
                                           bn_mode, momentum, eps, tok), tok)
 
@@ -319,7 +357,7 @@ def nb1d(x, weights, biases, dilated, bn1=None, bn2=None, bn_mode=0, drop_scale=
         g1, be1, rm1, rv1 = bn1
         g2, be2, rm2, rv2 = bn2
     tok = _ReluToken()
-    return _tag_output(_Nb1d.apply(x, weights[0], biases[0], weights[1], biases[1], weights[2], biases[2],
+    return _tag_output(_apply(_Nb1d, x, weights[0], biases[0], weights[1], biases[1], weights[2], biases[2],
                                    weights[3], biases[3], g1, be1, g2, be2, rm1, rv1, rm2, rv2,
                                    drop_scale, dilated, bn_mode, momentum, eps, tok), tok)
 
@@ -345,11 +383,17 @@ class _Nb1dChain(torch.autograd.Function):
         per_block = []
         for i, m in enumerate(meta):
             w0, b0, w1, b1, w2, b2, w3, b3, g1, be1, g2, be2 = flat[i * 12:(i + 1) * 12]
-            ws_ = [_param(t) for t in (w0, w1, w2, w3)]
-            bs_ = [_param(t) for t in (b0, b1, b2, b3)]
             mode = m["mode"]
-            bn1 = _Bn(mode, g1, be1, m["rm1"], m["rv1"], m["momentum"], m["eps"], need)
-            bn2 = _Bn(mode, g2, be2, m["rm2"], m["rv2"], m["momentum"], m["eps"], need)
+            if need:
+                ws_ = [_param(t) for t in (w0, w1, w2, w3)]
+                bs_ = [_param(t) for t in (b0, b1, b2, b3)]
+            else:       # inference: only the pointers are used, no detached views are created
+                ws_ = [_plain(t) for t in (w0, w1, w2, w3)]
+                bs_ = [_plain(t) for t in (b0, b1, b2, b3)]
+            bn1 = bn2 = _NO_BN
+            if mode:
+                bn1 = _Bn(mode, g1, be1, m["rm1"], m["rv1"], m["momentum"], m["eps"], need)
+                bn2 = _Bn(mode, g2, be2, m["rm2"], m["rv2"], m["momentum"], m["eps"], need)
             ds = m["drop_scale"]
             ds = None if ds is None else ds.to(torch.float32).contiguous()
             y = torch.empty_like(x)
@@ -449,7 +493,7 @@ def nb1d_chain(x, blocks):
         w, bi = b["weights"], b["biases"]
         flat += [w[0], bi[0], w[1], bi[1], w[2], bi[2], w[3], bi[3], g1, be1, g2, be2]
     tok = _ReluToken()
-    return _tag_output(_Nb1dChain.apply(x, meta, tok, *flat), tok)
+    return _tag_output(_apply(_Nb1dChain, x, meta, tok, *flat), tok)
 
 
 def conv_pair_pack(w_first, w_second):
@@ -537,7 +581,7 @@ def upsampler(x, w, b, bn_weight=None, bn_bias=None, running_mean=None, running_
               momentum=0.1, eps=1e-3):
     """UpsamplerBlock.forward of the reference (train/erfnet_blocks.py:84-88) on the GPU."""
     tok = _ReluToken()
-    return _tag_output(_Upsampler.apply(x, w, b, bn_weight if bn_mode else None,
+    return _tag_output(_apply(_Upsampler, x, w, b, bn_weight if bn_mode else None,
                                         bn_bias if bn_mode else None, running_mean, running_var, bn_mode,
                                         momentum, eps, tok), tok)
 
@@ -586,7 +630,7 @@ class _OutConv(torch.autograd.Function):
 def outconv(x, w, b):
     """nn.ConvTranspose2d(Cin, ncls, 2, stride=2) (train/net_classification.py:56,64) on the GPU.
     Returns NCHW-contiguous logits."""
-    return _OutConv.apply(x, w, b)
+    return _apply(_OutConv, x, w, b)
 
 
 def outconv_softmax(x, w, b):
@@ -660,7 +704,7 @@ class _Conv2d(torch.autograd.Function):
 def conv2d(x, w, b, relu=False):
     """nn.Conv2d with a 1x1 or 3x3 kernel, stride 1, 'same' padding (Encoder.output_conv,
     eval/erfnet.py:85; LadderBlock.conv, train/erfnet_blocks.py:145), optionally fused with ReLU."""
-    return _Conv2d.apply(x, w, b, relu)
+    return _apply(_Conv2d, x, w, b, relu)
 
 
 # ------------------------------------------------------------------------------ CrossEntropyLoss2d
