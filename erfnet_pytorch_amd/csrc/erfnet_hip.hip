@@ -363,6 +363,9 @@ int run_pair(const PairDesc &pd, int NC, int tile, hipStream_t st)
         pair_f32_kernel<64, 128, 4, 2><<<dim3(pd.nlines, 2, 1), 256, 0, st>>>(pd);
     else if (NC == 128 && tile == 64 && wide) pair_f32_kernel<64, 128, 8><<<pd.nlines, 512, 0, st>>>(pd);
     else if (NC == 64 && tile == 128 && wide) pair_f32_kernel<128, 64, 8><<<pd.nlines, 512, 0, st>>>(pd);
+    // the large tiles always take eight waves (four would need more registers than a wave may hold)
+    else if (NC == 128 && tile == 128 && force_nw != 4) pair_f32_kernel<128, 128, 8><<<pd.nlines, 512, 0, st>>>(pd);
+    else if (NC == 64 && tile == 256 && force_nw != 4) pair_f32_kernel<256, 64, 8><<<pd.nlines, 512, 0, st>>>(pd);
     else if (NC == 128 && tile == 64) pair_f32_kernel<64, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);
     else if (NC == 128 && tile == 128) pair_f32_kernel<128, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);
     else if (NC == 64 && tile == 128) pair_f32_kernel<128, 64, 4><<<pd.nlines, 256, 0, st>>>(pd);
