@@ -310,6 +310,85 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnStatsDesc d)
     }
 }
 
+// Vectorised statistics for C % 4 == 0: a thread owns four channels (16-byte loads) and walks rows
+// b*RP + rr, b*RP + rr + G*RP, ... (RP = 1024 / C rows per block step, G blocks); a block's sums go,
+// as doubles, to its own row of `partial` [G][2C] — no atomics, so the result is bitwise
+// reproducible once bn_reduce_kernel has added the rows in a fixed order.
+struct BnStats4Desc {
+    BnStatsDesc s;
+    double *partial;       // [gridDim.x][2C]
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_stats4_kernel(const BnStats4Desc dd)
+{
+    const BnStatsDesc &d = dd.s;
+    __shared__ float red[2][1024];
+    const int C = d.C, C4 = C / 4;
+    const int RP = 256 / C4;                          // rows per block step (C <= 256: RP >= 4)
+    const int cq = threadIdx.x % C4, rr = threadIdx.x / C4;
+    f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (rr < RP) {
+        f32x4 mean = s0, inv = s0;
+        if (BWD) {
+            mean = *reinterpret_cast<const f32x4 *>(d.mean + 4 * cq);
+            inv = *reinterpret_cast<const f32x4 *>(d.invstd + 4 * cq);
+        }
+        for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(d.x + r * C + 4 * cq);
+            if (BWD) {
+                f32x4 g = *reinterpret_cast<const f32x4 *>(d.gy + r * C + 4 * cq);
+                if (d.mask) {
+                    const f32x4 mk = *reinterpret_cast<const f32x4 *>(d.mask + r * C + 4 * cq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = mk[e] > 0.0f ? g[e] : 0.0f;
+                }
+                if (d.nscale) {
+                    const f32x4 ns = *reinterpret_cast<const f32x4 *>(d.nscale + (r / d.pix_per_image) * C + 4 * cq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] *= ns[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += g[e]; s1[e] += g[e] * (xv[e] - mean[e]) * inv[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][rr * C + 4 * cq + e] = s0[e];
+            red[1][rr * C + 4 * cq + e] = s1[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        double a = 0.0;
+        for (int k = 0; k < RP; ++k) a += red[which][k * C + c];
+        dd.partial[(long long)blockIdx.x * 2 * C + i] = a;
+    }
+}
+
+// sums[i] = sum over the G rows of partial[.][i], i < n (= 2C): 32 elements x 8 row groups per block,
+// the group sums added in a fixed order.
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const double *partial, double *sums, int G, int n)
+{
+    __shared__ double red[8][33];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + e;
+    double a = 0.0;
+    if (idx < n)
+        for (int i = g; i < G; i += 8) a += partial[(long long)i * n + idx];
+    red[g][e] = a;
+    __syncthreads();
+    if (g != 0 || idx >= n) return;
+    double tot = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) tot += red[k][e];
+    sums[idx] = tot;
+}
+
 // mean / invstd from the sums; running statistics updated as nn.BatchNorm2d does in training
 // (momentum, unbiased variance).
 __global__ void bn_finalize_kernel(const double *sums, float *save_mean, float *save_invstd,

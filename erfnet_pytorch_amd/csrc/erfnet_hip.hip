@@ -685,6 +685,47 @@ int launch_mask(const float *gy, const float *mask, float *out, long long M, int
     return launch_elt(gy, out, e, M, C, 1, st);
 }
 
+// Blocks of the vectorised statistics kernel for M rows of C channels (and the rows of its partial
+// buffer): enough to fill the chip, at least a few block steps of rows each.
+int bn_stats_blocks(long long M, int C)
+{
+    const int rp = 256 / (C / 4);
+    long long g = (M + rp * 4 - 1) / (rp * 4);
+    if (g > 1024) g = 1024;
+    return g < 1 ? 1 : (int)g;
+}
+size_t bn_scratch_bytes(long long M, int C)
+{
+    return sizeof(double) * 2 * (size_t)C * ((size_t)bn_stats_blocks(M, C) + 1) + 512;
+}
+
+// sums[0..2C) of a statistics pass.  C % 4 == 0 with 16-byte aligned tensors: per-block partial rows
+// and a fixed-order reduction; otherwise the scalar kernel with double atomics.
+int bn_stats_launch(const BnStatsDesc &s, bool bwd, Arena &ar, hipStream_t st)
+{
+    const int C = s.C;
+    const bool vec = C % 4 == 0 && aligned16(s.x) && (!bwd || (aligned16(s.gy) && aligned16(s.mean) && aligned16(s.invstd) &&
+                     (!s.mask || aligned16(s.mask)) && (!s.nscale || aligned16(s.nscale))));
+    if (vec) {
+        const int G = bn_stats_blocks(s.M, C);
+        double *partial = (double *)ar.take(sizeof(double) * 2 * (size_t)C * G);
+        if (!partial) return fail("workspace too small for BatchNorm partial sums");
+        BnStats4Desc d4 = {s, partial};
+        if (bwd) bn_stats4_kernel<true><<<G, 256, 0, st>>>(d4);
+        else bn_stats4_kernel<false><<<G, 256, 0, st>>>(d4);
+        CHECK_LAUNCH("bn_stats4_kernel");
+        bn_reduce_kernel<<<(2 * C + 31) / 32, 256, 0, st>>>(partial, s.sums, G, 2 * C);
+        CHECK_LAUNCH("bn_reduce_kernel");
+        return 0;
+    }
+    hipMemsetAsync(s.sums, 0, sizeof(double) * 2 * C, st);
+    const unsigned grid = (unsigned)((s.M + s.rows_per_block - 1) / s.rows_per_block);
+    if (bwd) bn_stats_kernel<true><<<grid, 256, 0, st>>>(s);
+    else bn_stats_kernel<false><<<grid, 256, 0, st>>>(s);
+    CHECK_LAUNCH("bn_stats_kernel");
+    return 0;
+}
+
 // Batch statistics of pre [M][C] -> bn->save_mean / save_invstd (+ running stats).
 int bn_train_stats(const erf_bn_t *bn, const float *pre, long long M, int C, Arena &ar, hipStream_t st)
 {
@@ -692,11 +733,9 @@ int bn_train_stats(const erf_bn_t *bn, const float *pre, long long M, int C, Are
     if (!bn->save_mean || !bn->save_invstd) return fail("BatchNorm train mode needs save_mean/save_invstd");
     double *sums = (double *)ar.take(sizeof(double) * 2 * C);
     if (!sums) return fail("workspace too small for BatchNorm sums");
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
     const int rows = 2048;
     BnStatsDesc s = {pre, nullptr, nullptr, nullptr, nullptr, nullptr, sums, M, C, 1, rows};
-    bn_stats_kernel<false><<<(unsigned)((M + rows - 1) / rows), 256, 0, st>>>(s);
-    CHECK_LAUNCH("bn_stats_kernel");
+    if (bn_stats_launch(s, false, ar, st)) return 1;
     bn_finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(sums, bn->save_mean, bn->save_invstd, bn->running_mean,
                                                     bn->running_var, M, C, bn->momentum, bn->eps);
     CHECK_LAUNCH("bn_finalize_kernel");
@@ -713,11 +752,9 @@ int bn_backward(const erf_bn_t *bn, const float *pre, const float *gy, const flo
     if (!bn->save_mean || !bn->save_invstd) return fail("BatchNorm backward needs save_mean/save_invstd");
     double *sums = (double *)ar.take(sizeof(double) * 2 * C);
     if (!sums) return fail("workspace too small for BatchNorm sums");
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
     const int rows = 2048;
     BnStatsDesc s = {pre, gy, mask, nscale, bn->save_mean, bn->save_invstd, sums, M, C, pix_per_image, rows};
-    bn_stats_kernel<true><<<(unsigned)((M + rows - 1) / rows), 256, 0, st>>>(s);
-    CHECK_LAUNCH("bn_stats_kernel");
+    if (bn_stats_launch(s, true, ar, st)) return 1;
     BnBwdDesc b = {pre, gy, mask, nscale, bn->gamma, bn->save_mean, bn->save_invstd, sums,
                    dx, dgamma, dbeta, M, C, pix_per_image, bn->mode == 2};
     bn_bwd_apply_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(b);
@@ -1259,7 +1296,7 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     } else if (plan_igemm(d[1], ar, pk[1]) || plan_igemm(d[0], ar, pk[0])) return 1;
     if (launch_pack(pk, 4, st)) return 1;
     // BatchNorm scratch first; the slabs of the four weight gradients follow it
-    const size_t bn_bytes = 2 * (sizeof(double) * 2 * (size_t)C + 256);
+    const size_t bn_bytes = 2 * bn_scratch_bytes(M, C);
     void *pbn = ar.take(bn_bytes);
     if (!pbn) return fail("non_bottleneck_1d backward: workspace too small");
     Arena bn_ar(pbn, bn_bytes);
