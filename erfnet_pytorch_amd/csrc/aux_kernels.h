@@ -370,22 +370,24 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const BnStats4Desc dd)
     }
 }
 
-// sums[i] = sum over the G rows of partial[.][i], i < n (= 2C): 32 elements x 8 row groups per block,
-// the group sums added in a fixed order.
+// sums[i] = sum over the G rows of partial[.][i], i < n (= 2C): a block takes 8 elements x 32 row
+// groups (thread (g, e) adds rows g, g+32, ...), the group sums are then added in a fixed order.
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const double *partial, double *sums, int G, int n)
 {
-    __shared__ double red[8][33];
-    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + e;
+    __shared__ double red[32][9];
+    const int e = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int idx = blockIdx.x * 8 + e;
     double a = 0.0;
-    if (idx < n)
-        for (int i = g; i < G; i += 8) a += partial[(long long)i * n + idx];
+    if (idx < n) {
+#pragma unroll 4
+        for (int i = g; i < G; i += 32) a += partial[(long long)i * n + idx];
+    }
     red[g][e] = a;
     __syncthreads();
     if (g != 0 || idx >= n) return;
     double tot = red[0][e];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) tot += red[k][e];
+    for (int k = 1; k < 32; ++k) tot += red[k][e];
     sums[idx] = tot;
 }
 

@@ -691,7 +691,7 @@ int bn_stats_blocks(long long M, int C)
 {
     const int rp = 256 / (C / 4);
     long long g = (M + rp * 4 - 1) / (rp * 4);
-    if (g > 1024) g = 1024;
+    if (g > 512) g = 512;
     return g < 1 ? 1 : (int)g;
 }
 size_t bn_scratch_bytes(long long M, int C)
@@ -714,7 +714,7 @@ int bn_stats_launch(const BnStatsDesc &s, bool bwd, Arena &ar, hipStream_t st)
         if (bwd) bn_stats4_kernel<true><<<G, 256, 0, st>>>(d4);
         else bn_stats4_kernel<false><<<G, 256, 0, st>>>(d4);
         CHECK_LAUNCH("bn_stats4_kernel");
-        bn_reduce_kernel<<<(2 * C + 31) / 32, 256, 0, st>>>(partial, s.sums, G, 2 * C);
+        bn_reduce_kernel<<<(2 * C + 7) / 8, 256, 0, st>>>(partial, s.sums, G, 2 * C);
         CHECK_LAUNCH("bn_reduce_kernel");
         return 0;
     }
