@@ -277,8 +277,8 @@ bool pair_enabled() { return g_sw_pair.on(); }
 // Tile variant (block pixels) for a line of L pixels and NC channels, 0 = none.
 int pair_tile(int NC, int L)
 {
-    if (NC == 128) return L <= 64 ? (L > 32 ? 64 : 0) : (L <= 128 ? 128 : 0);
-    if (NC == 64) return L <= 128 ? (L > 64 ? 128 : 0) : (L <= 256 ? 256 : 0);
+    if (NC == 128) return L <= 16 ? 0 : (L <= 32 ? 32 : (L <= 64 ? 64 : (L <= 128 ? 128 : 0)));
+    if (NC == 64) return L <= 32 ? 0 : (L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 256 ? 256 : 0)));
     return 0;
 }
 
@@ -366,6 +366,8 @@ int run_pair(const PairDesc &pd, int NC, int tile, hipStream_t st)
     // the large tiles always take eight waves (four would need more registers than a wave may hold)
     else if (NC == 128 && tile == 128 && force_nw != 4) pair_f32_kernel<128, 128, 8><<<pd.nlines, 512, 0, st>>>(pd);
     else if (NC == 64 && tile == 256 && force_nw != 4) pair_f32_kernel<256, 64, 8><<<pd.nlines, 512, 0, st>>>(pd);
+    else if (NC == 128 && tile == 32) pair_f32_kernel<32, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);
+    else if (NC == 64 && tile == 64) pair_f32_kernel<64, 64, 4><<<pd.nlines, 256, 0, st>>>(pd);
     else if (NC == 128 && tile == 64) pair_f32_kernel<64, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);
     else if (NC == 128 && tile == 128) pair_f32_kernel<128, 128, 4><<<pd.nlines, 256, 0, st>>>(pd);
     else if (NC == 64 && tile == 128) pair_f32_kernel<128, 64, 4><<<pd.nlines, 256, 0, st>>>(pd);
@@ -420,6 +422,9 @@ bool wgrad_line_ok(const WgradDesc *dd, int n)
         const int *td = along_h ? e.tdh : e.tdw;
         if (!(along_h || along_w) || td[1] != 0 || td[0] != -td[2] || td[2] < 1 || td[2] > 16) return false;
         if ((long long)e.N * e.GH * e.GW * NC >= (1LL << 29)) return false;
+        // a line is cut into 64-position segments: short lines would leave most MFMA rows empty
+        const int len = along_h ? e.GH : e.GW;
+        if (len * 10 < ((len + 63) / 64) * 64 * 7) return false;
     }
     return true;
 }

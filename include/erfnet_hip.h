@@ -137,8 +137,8 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
  * mid = act(conv_first(x) + b_first);  y = act(conv_second(mid) + b_second [+ residual])
  * first_axis: 1 = the first convolution runs along W (kernel (1,3)) and the second along H
  * (kernel (3,1)); 0 = the other way round.  A block computes a whole image line of the second
- * convolution (a column for first_axis = 1), so that line must fit a tile: C = 128 with 33..128
- * pixels per line, C = 64 with 65..256; otherwise the call is rejected
+ * convolution (a column for first_axis = 1), so that line must fit a tile: C = 128 with 17..128
+ * pixels per line, C = 64 with 33..256; otherwise the call is rejected
  * and the caller uses erf_nb1d_forward, which picks the launch plan itself.
  * Weights are repacked once with erf_conv_pair_pack (torch layout [C][C][3] each, `packed` holds
  * 2*3*C*C floats) and may then serve any number of forward calls — at inference they never change.

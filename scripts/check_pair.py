@@ -52,7 +52,7 @@ def case(n, c, h, w, d, reps=10):
 
 
 ok = True
-for shape in [(2, 128, 40, 72, 2), (2, 64, 72, 40, 1), (1, 128, 64, 24, 16), (6, 128, 64, 128, 2), (6, 128, 64, 128, 16),
+for shape in [(4, 128, 28, 28, 2), (4, 128, 28, 28, 16), (4, 64, 56, 56, 1), (3, 128, 17, 40, 4), (2, 128, 40, 72, 2), (2, 64, 72, 40, 1), (1, 128, 64, 24, 16), (6, 128, 64, 128, 2), (6, 128, 64, 128, 16),
               (6, 64, 128, 256, 1)]:
     ok = case(*shape) and ok
 print("ALL BITWISE EQUAL" if ok else "MISMATCH")

@@ -448,7 +448,8 @@ def test_graphed_forward_replays_the_eager_result():
 
 
 @pytest.mark.parametrize("C_,d,N,H,W", [(128, 2, 2, 40, 24), (128, 16, 1, 64, 20), (64, 1, 2, 72, 20),
-                                        (64, 2, 1, 128, 12)])
+                                        (64, 2, 1, 128, 12), (128, 8, 3, 28, 28), (64, 1, 2, 56, 56),
+                                        (128, 1, 1, 17, 33)])
 @pytest.mark.parametrize("bn_mode", [0, 1, 2])
 def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
     """Two chained 1-D convolutions in one launch (pair_f32_kernel, image columns as block tiles)
