@@ -1643,4 +1643,27 @@ int erf_iou_add_batch(const long long *pred, const long long *target, long long 
     return 0;
 }
 
+int erf_accuracy_counts(const float *scores, const long long *target, int N, int K, int H, int W,
+                        long long *counts, void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (K < 1 || K > IOU_MAX_CLASSES) return fail("accuracy: 1..%d classes (got %d)", IOU_MAX_CLASSES, K);
+    if (!scores || !target || !counts) return fail("accuracy: null pointer");
+    const long long P = (long long)N * H * W;
+    if (P <= 0) return 0;
+    AccDesc d;
+    d.scores = scores; d.target = target; d.P = P; d.HW = H * W; d.K = K; d.counts = counts;
+    long long blocks = (P + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    d.blocks = (int)blocks;
+    d.partial = (unsigned *)ar.take((size_t)blocks * 2 * K * sizeof(unsigned));
+    if (!d.partial) return fail("accuracy: workspace too small");
+    acc_count_kernel<<<(unsigned)blocks, 256, 0, st>>>(d);
+    CHECK_LAUNCH("acc_count_kernel");
+    acc_sum_kernel<<<1, 256, 0, st>>>(d);
+    CHECK_LAUNCH("acc_sum_kernel");
+    return 0;
+}
+
 }  // extern "C"

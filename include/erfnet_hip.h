@@ -214,6 +214,14 @@ int erf_iou_add_batch(const long long *pred, const long long *target, long long 
                       int n_classes, int ignore_index, long long *counts, void *ws, size_t ws_bytes,
                       void *stream);
 
+/* ---- ClassificationAccuracy / MeanAccuracy (train/evaluation_functions.py:133-163) ---------------
+ * scores: NCHW fp32 [N,K,H,W] (logits or probabilities); target: int64 [N,H,W].  counts: int64
+ * [2][K]; the call ADDS, per label class c, counts[0][c] += pixels labelled c whose argmax over the
+ * K scores is c, counts[1][c] += pixels labelled c.  Labels outside [0,K) (the ignore label -1) are
+ * skipped.  Accuracy = sum(correct) / sum(total); class accuracy = correct[c] / total[c]. */
+int erf_accuracy_counts(const float *scores, const long long *target, int N, int K, int H, int W,
+                        long long *counts, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -644,6 +644,31 @@ def test_alternative_kernel_paths_agree(C_, d, N, H, W):
         gu.check_arrays(u.cpu().numpy(), v.cpu().numpy(), 1e-5, 1e-4, what=f"tensor{i}", scale_rtol=2e-5)
 
 
+def test_accuracy_metrics_match_reference_formulas():
+    """ClassificationAccuracy / MeanAccuracy on the GPU (erf_accuracy_counts) against the reference's
+    formulas (train/evaluation_functions.py:133-163) evaluated with torch ops: same accuracy, same
+    per-class values (nan for absent classes), labels -1 ignored."""
+    from erfnet_pytorch_amd.evaluation_functions import ClassificationAccuracy, MeanAccuracy
+    g = torch.Generator().manual_seed(5)
+    for n, k, h, w, present in ((2, 20, 64, 96, 20), (1, 5, 33, 47, 3), (3, 7, 16, 16, 7)):
+        prob = torch.randn(n, k, h, w, generator=g)
+        tgt = torch.randint(-1, present, (n, h, w), generator=g)
+        # make some pixels certainly correct so the accuracy is not ~1/k everywhere
+        idx = torch.rand(n, h, w, generator=g) < 0.4
+        boost = torch.nn.functional.one_hot(tgt.clamp(min=0), k).permute(0, 3, 1, 2).float() * 8.0
+        prob = prob + boost * idx.unsqueeze(1)
+        n0 = launches()
+        acc = ClassificationAccuracy()(prob.to(DEV), tgt.to(DEV))
+        mean_acc, class_acc = MeanAccuracy(k)(prob.to(DEV), tgt.to(DEV))
+        assert launches() - n0 == 4
+        mx = prob.argmax(dim=1)
+        ref_acc = (mx == tgt).sum().float() / (tgt >= 0).sum().float()
+        ref_cls = np.array([float(((mx == tgt) & (tgt == c)).sum().float() / (tgt == c).sum().float()) for c in range(k)])
+        assert abs(float(acc) - float(ref_acc)) < 1e-6
+        np.testing.assert_allclose(class_acc, ref_cls, rtol=1e-6, equal_nan=True)
+        assert abs(float(mean_acc) - float(np.nanmean(ref_cls))) < 1e-6
+
+
 def test_predict_labels_equals_argmax_of_logits():
     """ERFNet.predict_labels (erf_outconv_argmax) against max(1)[1] of the logits of the same
     network: identical labels, int64 [N,1,H,W]; the CPU path agrees as well."""
