@@ -772,3 +772,26 @@ def test_full_size_properties_batch6():
     assert torch.isfinite(y_a).all()
     assert torch.equal(y_a, y_b)
     assert torch.allclose(y_a[2:3], y_1, atol=1e-5, rtol=1e-5)
+
+
+def test_training_step_is_bitwise_reproducible():
+    """Two identical forward/backward passes of the 20-class network at 2x3x256x512 give bit-identical
+    logits and gradients: every reduction in the kernels runs in a fixed order (no atomics on
+    floating-point data), and a race between blocks would show up here."""
+    net = gu.fill_state_dict(make_model("net_classification_20"), tag="trainstep").to(DEV).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(2, 3, 256, 512, generator=g).to(DEV)
+    lab = torch.randint(-1, 20, (2, 256, 512), generator=g).to(DEV)
+    runs = []
+    for _ in range(2):
+        net.zero_grad(set_to_none=True)
+        out = first(net(x))
+        torch.nn.functional.cross_entropy(out, lab, ignore_index=-1).backward()
+        runs.append((out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert runs[0][1].keys() == runs[1][1].keys() and len(runs[0][1]) > 100
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
