@@ -644,12 +644,8 @@ int launch_up16_wgrad(WgradDesc &d, float *dw, float *db, int wsk, int wsn, int 
     d.ntaps = 9; d.Nout = 16;
     d.partial = ar.floats(slab * nsplit);
     if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
-    switch (KQ) {
-    case 1: up16_wgrad_kernel<1><<<(unsigned)nsplit, 256, 0, st>>>(d); break;
-    case 2: up16_wgrad_kernel<2><<<(unsigned)nsplit, 256, 0, st>>>(d); break;
-    case 3: up16_wgrad_kernel<3><<<(unsigned)nsplit, 256, 0, st>>>(d); break;
-    default: up16_wgrad_kernel<4><<<(unsigned)nsplit, 256, 0, st>>>(d); break;
-    }
+    // one 16-channel quad of the coarse side per block (blockIdx.y)
+    up16_wgrad_kernel<1><<<dim3((unsigned)nsplit, KQ, 1), 256, 0, st>>>(d);
     CHECK_LAUNCH("up16_wgrad_kernel");
     ReduceBatch rb;
     memset(&rb, 0, sizeof(rb));

@@ -134,6 +134,9 @@ __global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
     __shared__ float red[SLOTS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
+    // blockIdx.y selects the block's KQ channel quads of the coarse side (of d.K / 16 in total):
+    // fewer accumulators per wave, more waves in flight to hide the load latency
+    const int q0 = blockIdx.y * KQ, KQT = d.K / 16;
     const unsigned H = (unsigned)d.GH, W = (unsigned)d.GW, M = (unsigned)d.N * H * W, HW = H * W;
     const unsigned wsp = (unsigned)d.split_pixels / 4;            // multiple of 4 (host)
     const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
@@ -152,19 +155,32 @@ __global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
     struct Frag {
         float cs[4][KQ], fc[4];
     };
+    // coordinates of position m0 + g, kept per lane and advanced by 4 positions per call (the groups
+    // are loaded in ascending order): one division pair per wave instead of one per group
+    unsigned cn, cy, cx;
+    {
+        const unsigned p0 = (wbeg < M ? wbeg : 0u) + g;
+        cn = p0 / HW;
+        const unsigned rem = p0 - cn * HW;
+        cy = rem / W;
+        cx = rem - cy * W;
+    }
     auto load_group = [&](unsigned m0, Frag &f) {
         const unsigned p = m0 + g;
         const bool valid = p < wend;
-        const unsigned pp = valid ? p : 0;
-        const unsigned n = pp / HW, rem = pp - n * HW;
-        const unsigned y = rem / W, x = rem - y * W;
+        const unsigned n = cn, y = cy, x = cx;
+        cx += 4;
+        while (cx >= W) {
+            cx -= W;
+            if (++cy == H) { cy = 0; ++cn; }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const unsigned ys = y + (s >> 1), xx = x + (s & 1);
             const bool ok = valid && ys < H && xx < W;
             const unsigned off = (((n * H + ys) * W + xx) * d.in_C + d.in_coff + i) * 4u;
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) f.cs[s][q] = buf_load1(r_c, ok ? off + q * 64u : ERF_OOB);
+            for (int q = 0; q < KQ; ++q) f.cs[s][q] = buf_load1(r_c, ok ? off + (q0 + q) * 64u : ERF_OOB);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -226,15 +242,16 @@ __global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
         }
         __syncthreads();
     }
-    // slab: weights, 9 bias rows (row 0 carries the fine-side sums), coarse-side sums
-    const int slab = NW_ + 9 * 16 + 16 * KQ;
+    // slab of the whole layer: [9][K][16] weights, 9 bias rows (row 0 carries the fine-side sums,
+    // written by the first quad block), [K] coarse-side sums; this block fills its quads' share
+    const int nwt = 9 * KQT * 256;
+    const int slab = nwt + 9 * 16 + 16 * KQT;
     float *P = d.partial + (long long)blockIdx.x * slab;
-    for (int e = tid; e < slab; e += 256) {
-        float v;
-        if (e < NW_) v = red[e];
-        else if (e < NW_ + 16) v = red[e];
-        else if (e < NW_ + 9 * 16) v = 0.0f;
-        else v = red[NW_ + 16 + (e - NW_ - 9 * 16)];
-        P[e] = v;
+    for (int e = tid; e < NW_; e += 256) {
+        const int t = e / (KQ * 256), rest = e - t * (KQ * 256);      // rest = (q*16 + krow)*16 + j
+        P[(t * KQT + q0) * 256 + rest] = red[e];
     }
+    if (blockIdx.y == 0)
+        for (int e = tid; e < 9 * 16; e += 256) P[nwt + e] = e < 16 ? red[NW_ + e] : 0.0f;
+    for (int e = tid; e < 16 * KQ; e += 256) P[nwt + 9 * 16 + 16 * q0 + e] = red[NW_ + 16 + e];
 }
