@@ -203,16 +203,23 @@ def main():
     model = build_model(args.model).to(device).train()
     reducer = GradientReducer(model, direct_write=True)
     reducer.broadcast_parameters(0)
-    params = [p for p in model.parameters() if p.requires_grad]
-    # the reference's optimiser settings (train/main.py:43-46,213); `fused` only picks torch's
-    # single-kernel implementation of the same update
-    opt = torch.optim.Adam(params, 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6, fused=True)
     from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
     crit = CrossEntropyLoss2d()       # train/main.py:186-188
 
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     images = torch.rand(args.batch, 3, HEIGHT, WIDTH, generator=g).to(device)
     labels = torch.randint(-1, CLASSES, (args.batch, HEIGHT, WIDTH), generator=g).to(device)
+
+    # Set-up pass (no update): one backward tells the reducer which parameters take part; they are
+    # then laid out in flat buffers next to their gradient buckets.  The optimiser keeps the
+    # reference's settings (train/main.py:43-46,213); on the flat buffers torch's fused Adam is the
+    # same element-wise update in one launch per bucket, and parameters that never get a gradient
+    # are skipped as Adam skips them.
+    reducer.zero_grad()
+    crit(logits_of(model(images)), labels).backward()
+    reducer.finish()
+    params = reducer.flatten_parameters()
+    opt = torch.optim.Adam(params, 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6, fused=True)
 
     def step():
         reducer.zero_grad()

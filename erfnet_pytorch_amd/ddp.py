@@ -164,6 +164,32 @@ class GradientReducer:
             flat.div_(self.world)
         self._work = []
 
+    def flatten_parameters(self):
+        """Move the parameters that receive gradients into flat buffers laid out like the gradient
+        buckets and return one ``nn.Parameter`` per bucket whose ``.grad`` is that bucket.  An
+        element-wise optimiser (Adam, SGD) built on the returned list performs exactly the update
+        it would perform tensor by tensor — parameters without a gradient are skipped either way —
+        in one launch per bucket instead of one pass over 150 small tensors.  Call after the first
+        backward pass + ``finish()`` (the set of live parameters is known from then on); the
+        module's parameters become views into the flat buffers."""
+        if not self._first_step_done:
+            raise RuntimeError("flatten_parameters() needs one backward pass and finish() first")
+        flats = []
+        with torch.no_grad():
+            for flat_g, ps in self._buckets:
+                flat_p = torch.empty_like(flat_g)
+                off = 0
+                for p in ps:
+                    n = p.numel()
+                    flat_p[off:off + n].copy_(p.data.reshape(-1))
+                    p.data = flat_p[off:off + n].view_as(p)
+                    off += n
+                fp = torch.nn.Parameter(flat_p, requires_grad=True)
+                fp.grad = flat_g
+                flats.append(fp)
+        self._flat_params = flats
+        return flats
+
     @property
     def bucket_sizes(self):
         return [flat.numel() * flat.element_size() for flat, _ in self._buckets]

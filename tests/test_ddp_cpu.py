@@ -92,3 +92,34 @@ def test_reducer_matches_single_process(tmp_path):
     n_all = sum(1 for _ in model.parameters())
     assert r0["n_active"] == len(ref) < n_all
     assert len(r0["buckets"]) >= 2
+
+
+def test_flat_parameters_give_the_same_adam_steps():
+    """GradientReducer.flatten_parameters(): Adam on the flat buffers (one per gradient bucket) must
+    leave every module parameter bit-identical to Adam on the individual tensors, parameters that
+    never receive a gradient stay untouched, and the module keeps working on the views."""
+    sys.path.insert(0, ROOT)
+    from erfnet_pytorch_amd.ddp import GradientReducer
+    x, y = _batch(0)
+    results = []
+    for flat in (False, True):
+        model = _model()
+        red = GradientReducer(model, bucket_bytes=128 << 10)
+        # set-up pass without an update: discovers the live parameters
+        red.zero_grad()
+        torch.nn.functional.l1_loss(model(x), y).backward()
+        red.finish()
+        params = red.flatten_parameters() if flat else [p for p in model.parameters() if p.requires_grad]
+        opt = torch.optim.Adam(params, 1e-3, eps=1e-4, weight_decay=1e-6)
+        for _ in range(3):
+            red.zero_grad()
+            torch.nn.functional.l1_loss(model(x), y).backward()
+            red.finish()
+            opt.step()
+        results.append({k: p.detach().clone() for k, p in model.named_parameters()})
+        if flat:
+            assert len(params) == len(red.bucket_sizes) < len(list(model.parameters())) // 4
+    a, b = results
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
