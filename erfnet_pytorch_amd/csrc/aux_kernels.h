@@ -48,6 +48,41 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
                 xin[ci * 9 + kh * 3 + kw] = v;
             }
     float *o = d.out + m * Cout;
+    if (d.Cc == 13 && !d.epi.nscale && !d.epi.res && !d.epi.mask) {
+        // the network's own first block (3 -> 16 channels): all 16 outputs of the pixel are formed
+        // in registers and leave as four 16-byte stores (same arithmetic as the general path below)
+        float v[16];
+#pragma unroll
+        for (int co = 0; co < 13; ++co) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 27; ++e) acc = fmaf(xin[e], ws[co * 28 + e], acc);
+            float sc, sh;
+            epi_channel_affine(d.epi, co, sc, sh);
+            v[co] = acc * sc + sh;
+        }
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const float a = xin[ci * 9 + 4], b = xin[ci * 9 + 5], c = xin[ci * 9 + 7], e = xin[ci * 9 + 8];
+            float mx = a;
+            if (b > mx) mx = b;
+            if (c > mx) mx = c;
+            if (e > mx) mx = e;
+            Epilogue ep = d.epi;
+            ep.bias = nullptr;
+            float sc, sh;
+            epi_channel_affine(ep, 13 + ci, sc, sh);
+            v[13 + ci] = mx * sc + sh;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 st;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st[e] = d.epi.relu ? fmaxf(v[q * 4 + e], 0.0f) : v[q * 4 + e];
+            *reinterpret_cast<f32x4 *>(o + q * 4) = st;
+        }
+        return;
+    }
     for (int co = 0; co < d.Cc; ++co) {
         float acc = 0.0f;
 #pragma unroll
