@@ -20,7 +20,9 @@ Design points
     (weight sharing) still accumulates through autograd; gradients therefore do NOT accumulate
     across several backward passes without ``zero_grad`` in between when this is on.
   * The payload is small (8.2 MB of fp32 for the 20-class network), i.e. latency-bound on xGMI:
-    few, large buckets beat many small ones.
+    few, large buckets beat many small ones.  Only the last bucket's all-reduce cannot overlap with
+    backward, so the bucket size should leave a small remainder for it (the 128-channel stage,
+    whose gradients come first, holds 6.3 of the 8.2 MB).
 """
 import torch
 import torch.distributed as dist
@@ -39,6 +41,8 @@ class GradientReducer:
         self._written = set()
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # RCCL averages inside the collective (ncclAvg); other backends sum and divide afterwards
+        self._avg_op = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.params = [p for p in module.parameters() if p.requires_grad]
         self._bucket_bytes = bucket_bytes
         self._active = None            # params known to receive gradients (after the first step)
@@ -132,8 +136,8 @@ class GradientReducer:
         if self.world == 1 and not self._always:
             return
         flat, _ = self._buckets[b]
-        self._work.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
-                           flat))
+        op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
+        self._work.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat))
         self._pending[b] = -1
 
     def finish(self):
@@ -161,7 +165,8 @@ class GradientReducer:
                     self._launch(b)
         for work, flat in self._work:
             work.wait()
-            flat.div_(self.world)
+            if not self._avg_op:
+                flat.div_(self.world)
         self._work = []
 
     def flatten_parameters(self):
