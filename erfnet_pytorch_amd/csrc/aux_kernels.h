@@ -487,6 +487,47 @@ __global__ __launch_bounds__(256) void elt_kernel(const EltDesc d)
     }
 }
 
+// The same pass for channel counts whose float4 columns divide the block (256 % (C/4) == 0) and
+// 16-byte addressable optional tensors: a thread keeps one channel quad, so the per-channel affine
+// is formed once, rows advance without any division, and every tensor moves as 16-byte accesses.
+__global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
+{
+    const int C = d.C, C4 = C / 4, RP = 256 / C4;
+    const int c = (threadIdx.x % C4) * 4, rr = threadIdx.x / C4;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) epi_channel_affine(d.epi, c + e, sc[e], sh[e]);
+    const Epilogue &ep = d.epi;
+    const bool has_res = ep.res != nullptr, has_mask = ep.mask != nullptr, has_ns = ep.nscale != nullptr;
+    const bool relu = ep.relu != 0;
+    for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(d.in + r * C + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] * sc[e] + sh[e];
+        if (has_ns) {
+            const f32x4 ns = *reinterpret_cast<const f32x4 *>(ep.nscale + (r / d.pix_per_image) * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] *= ns[e];
+        }
+        if (has_res) {
+            const f32x4 rs = *reinterpret_cast<const f32x4 *>(ep.res + r * ep.res_C + ep.res_coff + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += rs[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.0f);
+        }
+        if (has_mask) {
+            const f32x4 mk = *reinterpret_cast<const f32x4 *>(ep.mask + r * ep.mask_C + ep.mask_coff + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = mk[e] > 0.0f ? o[e] : 0.0f;
+        }
+        *reinterpret_cast<f32x4 *>(d.out + r * C + c) = o;
+    }
+}
+
 // BatchNorm backward apply: with g = gy*(mask>0)*nscale,
 //   train: dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M);  eval: dx = gamma*invstd*g.
 // dgamma = sum_gx, dbeta = sum_g are written by block 0.
@@ -531,6 +572,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdDesc d)
             }
         }
         *reinterpret_cast<f32x4 *>(d.dx + m * d.C + c) = o;
+    }
+}
+
+// Row-structured variant (256 % (C/4) == 0, 16-byte aligned tensors): per-channel constants once
+// per thread, no divisions, 16-byte accesses for the mask and the dropout factors as well.
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const BnBwdDesc d)
+{
+    const int C = d.C, C4 = C / 4, RP = 256 / C4;
+    const int c = (threadIdx.x % C4) * 4, rr = threadIdx.x / C4;
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < C; k += 256) {
+            if (d.dbeta) d.dbeta[k] = (float)d.sums[k];
+            if (d.dgamma) d.dgamma[k] = (float)d.sums[C + k];
+        }
+    const double invM = 1.0 / (double)d.M;
+    float gi[4], mean[4], inv[4], mg[4], mgx[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ch = c + e;
+        inv[e] = d.invstd[ch];
+        mean[e] = d.mean[ch];
+        gi[e] = (d.gamma ? d.gamma[ch] : 1.0f) * inv[e];
+        mg[e] = (float)(d.sums[ch] * invM);
+        mgx[e] = (float)(d.sums[C + ch] * invM);
+    }
+    const bool has_mask = d.mask != nullptr, has_ns = d.nscale != nullptr, training = d.training != 0;
+    for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(d.x + r * C + c);
+        f32x4 g = *reinterpret_cast<const f32x4 *>(d.gy + r * C + c);
+        if (has_mask) {
+            const f32x4 mk = *reinterpret_cast<const f32x4 *>(d.mask + r * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = mk[e] > 0.0f ? g[e] : 0.0f;
+        }
+        if (has_ns) {
+            const f32x4 ns = *reinterpret_cast<const f32x4 *>(d.nscale + (r / d.pix_per_image) * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] *= ns[e];
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (training) {
+                const float xh = (xv[e] - mean[e]) * inv[e];
+                o[e] = gi[e] * (g[e] - mg[e] - xh * mgx[e]);
+            } else {
+                o[e] = gi[e] * g[e];
+            }
+        }
+        *reinterpret_cast<f32x4 *>(d.dx + r * C + c) = o;
     }
 }
 

@@ -673,7 +673,17 @@ int launch_elt(const float *in, float *out, const Epilogue &epi, long long M, in
 {
     if (C % 4) return fail("element-wise pass needs C %% 4 == 0 (C = %d)", C);
     EltDesc e = {in, out, epi, M, C, pix_per_image};
-    elt_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(e);
+    const int C4 = C / 4;
+    const bool rows = C4 <= 256 && 256 % C4 == 0 && aligned16(in) && aligned16(out) &&
+                      (!epi.res || (epi.res_C % 4 == 0 && epi.res_coff % 4 == 0 && aligned16(epi.res))) &&
+                      (!epi.mask || (epi.mask_C % 4 == 0 && epi.mask_coff % 4 == 0 && aligned16(epi.mask))) &&
+                      (!epi.nscale || aligned16(epi.nscale));
+    if (rows) {
+        const long long steps = (M * C4 + 255) / 256;
+        elt_rows_kernel<<<(unsigned)(steps < 2048 ? (steps < 1 ? 1 : steps) : 2048), 256, 0, st>>>(e);
+    } else {
+        elt_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(e);
+    }
     CHECK_LAUNCH("elt_kernel");
     return 0;
 }
@@ -758,7 +768,14 @@ int bn_backward(const erf_bn_t *bn, const float *pre, const float *gy, const flo
     if (bn_stats_launch(s, true, ar, st)) return 1;
     BnBwdDesc b = {pre, gy, mask, nscale, bn->gamma, bn->save_mean, bn->save_invstd, sums,
                    dx, dgamma, dbeta, M, C, pix_per_image, bn->mode == 2};
-    bn_bwd_apply_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(b);
+    const int C4 = C / 4;
+    if (256 % C4 == 0 && aligned16(pre) && aligned16(gy) && aligned16(dx) && (!mask || aligned16(mask)) &&
+        (!nscale || aligned16(nscale))) {
+        const long long steps = (M * C4 + 255) / 256;
+        bn_bwd_apply_rows_kernel<<<(unsigned)(steps < 2048 ? (steps < 1 ? 1 : steps) : 2048), 256, 0, st>>>(b);
+    } else {
+        bn_bwd_apply_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(b);
+    }
     CHECK_LAUNCH("bn_bwd_apply_kernel");
     return 0;
 }
