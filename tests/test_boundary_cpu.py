@@ -194,3 +194,21 @@ def test_accuracy_metrics_cpu():
     assert float(ClassificationAccuracy()(prob, tgt)) == 0.5
     mean_acc, class_acc = MeanAccuracy(3)(prob, tgt)
     assert float(mean_acc) == 0.5 and class_acc[0] == 1.0 and np.isnan(class_acc[1]) and class_acc[2] == 0.0
+
+
+def test_mean_teacher_update_matches_reference_formula():
+    """copyWeightsToModelWithDiscount (multi-tensor form) against the per-parameter formula of
+    train/main.py:140-142; copyWeightsToModelNoGrad only freezes the teacher."""
+    import torch
+    from erfnet_pytorch_amd import mean_teacher, net_regression_small
+    torch.manual_seed(1)
+    student, teacher = net_regression_small.Net(), net_regression_small.Net()
+    with torch.no_grad():
+        for p in teacher.parameters():
+            p.add_(0.25)
+    want = [t.data * (1 - 0.01) + 0.01 * s.data for s, t in zip(student.parameters(), teacher.parameters())]
+    mean_teacher.copyWeightsToModelNoGrad(student, teacher)
+    assert not any(p.requires_grad for p in teacher.parameters())
+    mean_teacher.copyWeightsToModelWithDiscount(student, teacher, 0.01)
+    for w, t in zip(want, teacher.parameters()):
+        assert torch.allclose(w, t.data, rtol=1e-6, atol=1e-8)
