@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -868,6 +869,35 @@ ParityTaps parity_taps()
 
 }  // namespace
 
+// Scratch of erf_cross_entropy_forward_static: the block partial sums of the loss live in a device
+// array of the library's code object instead of a caller workspace (for callers that may not allocate).
+#define ERF_CE_STATIC_BYTES (1u << 20)
+static __device__ __align__(256) unsigned char scratch[ERF_CE_STATIC_BYTES];
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void *g_scratch_ptr[kMaxDevices];        // device address of `scratch` on each GPU (0 = not resolved yet)
+
+// Device address of this GPU's copy of `scratch`.  The array's name is only a host-side handle:
+// every use of the memory (kernel arguments, memsets, copies) goes through the resolved address.
+int static_scratch(void **out)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail("static scratch: hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return fail("static scratch: device ordinal %d not supported", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail("static scratch: hipGetSymbolAddress: %s", hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int erf_version(void) { return 100; }
@@ -1609,6 +1639,34 @@ int erf_cross_entropy_forward(const float *logits, const long long *target, floa
     else ce_fwd_kernel<false><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     CHECK_LAUNCH("ce_fwd_kernel");
     ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
+    CHECK_LAUNCH("ce_reduce_kernel");
+    return 0;
+}
+
+// ---- the same loss for callers that may not allocate (static scratch, see the top of the file)
+int erf_cross_entropy_forward_static(const float *logits, const long long *target, float *stats, float *lse,
+                                     int N, int K, int H, int W, long long ignore_index, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (K < 1) return fail("cross entropy: no classes");
+    if (N < 0 || H < 0 || W < 0) return fail("cross entropy: negative extent");
+    const long long P = (long long)N * H * W;
+    if (P == 0) return fail("cross entropy: empty input");
+    const long long blocks = (P + CE_BLOCK - 1) / CE_BLOCK;
+    const long long max_blocks = ERF_CE_STATIC_BYTES / (2 * sizeof(float));
+    if (blocks > max_blocks)
+        return fail("cross entropy (static scratch): %lld pixels exceed the limit of %lld", P,
+                    max_blocks * CE_BLOCK);
+    if (!logits || !target || !stats || !lse) return fail("cross entropy: null pointer");
+    void *sp = nullptr;
+    if (static_scratch(&sp)) return 1;
+    // every block overwrites its own pair of partial sums before the reduction reads them, so
+    // nothing of an earlier call's contents has to be cleared
+    CeDesc d = {logits, target, lse, (float *)sp, P, H * W, K, ignore_index};
+    if (K <= CE_MAX_K) ce_fwd_kernel<true><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
+    else ce_fwd_kernel<false><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
+    CHECK_LAUNCH("ce_fwd_kernel");
+    ce_reduce_kernel<<<1, 256, 0, st>>>((const float *)sp, (int)blocks, stats);
     CHECK_LAUNCH("ce_reduce_kernel");
     return 0;
 }

@@ -198,6 +198,18 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
 int erf_cross_entropy_forward(const float *logits, const long long *target, float *stats, float *lse,
                               int N, int K, int H, int W, long long ignore_index, void *ws,
                               size_t ws_bytes, void *stream);
+/* The same loss for callers that cannot allocate device memory or bring a workspace: code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
+ * reference.  The block partial sums go to a 1 MiB array inside the library's code object (one
+ * copy per GPU, held until the process ends), so the call allocates nothing and takes no `ws`;
+ * results equal erf_cross_entropy_forward bit for bit.  At most 33,554,432 pixels (N*H*W) per
+ * call; larger inputs are rejected.  The device whose stream is passed must be current.  All calls
+ * on one GPU share that array: calls that overlap in time on the same GPU (two streams) race;
+ * calls on one stream are ordered and need no clearing in between. */
+#define ERF_CE_STATIC_MAX_PIXELS 33554432LL
+int erf_cross_entropy_forward_static(const float *logits, const long long *target, float *stats,
+                                     float *lse, int N, int K, int H, int W, long long ignore_index,
+                                     void *stream);
 /* dlogits = d(stats[0])/d(logits) * gy[0]; gy is a device scalar (the upstream gradient). */
 int erf_cross_entropy_backward(const float *logits, const long long *target, const float *lse,
                                const float *stats, const float *gy, float *dlogits, int N, int K, int H,
