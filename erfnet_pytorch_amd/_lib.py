@@ -106,6 +106,16 @@ _PROTOS = {
                                              C.c_int, ll, vp]),
 }
 
+# bf16 variants: same argument lists (activation pointers are bf16 tensors, parameters stay fp32)
+for _n in ("erf_downsampler_forward", "erf_downsampler_backward", "erf_nb1d_forward", "erf_nb1d_chain_forward",
+           "erf_nb1d_backward", "erf_upsampler_forward", "erf_upsampler_backward", "erf_outconv_argmax",
+           "erf_outconv_backward", "erf_conv2d_forward", "erf_conv2d_backward", "erf_conv_pair_pack",
+           "erf_conv_pair_forward"):
+    _PROTOS[_n + "_bf16"] = _PROTOS[_n]
+# erf_outconv_forward_bf16 has one more argument: y_is_bf16 behind y
+_PROTOS["erf_outconv_forward_bf16"] = (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, vp])
+
 BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
 OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16 = 1, 2, 3
 

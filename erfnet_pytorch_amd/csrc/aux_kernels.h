@@ -1,6 +1,7 @@
 // Memory-bound companions of the implicit-GEMM kernels: the 3-channel network-input downsampler,
 // 2x2 max-pool (forward / backward), BatchNorm statistics / apply / backward, element-wise
-// gradient masking and the 2x2 stride-2 output transposed convolution.  All NHWC fp32.
+// gradient masking and the 2x2 stride-2 output transposed convolution.  NHWC activations stored as
+// fp32 or bf16 (template parameter T / AT), arithmetic in fp32.
 #pragma once
 #include "common.h"
 
@@ -9,15 +10,16 @@
 // one thread per output pixel.  x is read through its strides (NCHW images need no repacking).
 // Weights [Cc][3][3][3] and bias are staged in LDS (broadcast reads).  Output NHWC [*, Cc+3].
 struct FirstDownDesc {
-    const float *x;
+    const void *x;       // image, storage type T
     long long sn, sc, sh, sw;
     const float *w;      // [Cc][27]
-    float *out;          // [N][Ho][Wo][Cc+3]
+    void *out;           // [N][Ho][Wo][Cc+3], storage type T
     Epilogue epi;
     int N, H, W, Cc;
 };
 
 #define FD_MAX_CC 61
+template <typename T>
 __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc d)
 {
     __shared__ float ws[FD_MAX_CC * 28];
@@ -44,10 +46,10 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
                 const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
                 float v = 0.0f;
                 if (ih >= 0 && iw >= 0 && ih < d.H && iw < d.W)
-                    v = d.x[n * d.sn + ci * d.sc + ih * d.sh + iw * d.sw];
+                    v = Act<T>::ld1(d.x, n * d.sn + ci * d.sc + ih * d.sh + iw * d.sw);
                 xin[ci * 9 + kh * 3 + kw] = v;
             }
-    float *o = d.out + m * Cout;
+    const long long o0 = m * Cout;
     if (d.Cc == 13 && !d.epi.nscale && !d.epi.res && !d.epi.mask) {
         // the network's own first block (3 -> 16 channels): all 16 outputs of the pixel are formed
         // in registers and leave as four 16-byte stores (same arithmetic as the general path below)
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
             f32x4 st;
 #pragma unroll
             for (int e = 0; e < 4; ++e) st[e] = d.epi.relu ? fmaxf(v[q * 4 + e], 0.0f) : v[q * 4 + e];
-            *reinterpret_cast<f32x4 *>(o + q * 4) = st;
+            Act<T>::st4(d.out, o0 + q * 4, st);
         }
         return;
     }
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
         for (int e = 0; e < 27; ++e) acc = fmaf(xin[e], ws[co * 28 + e], acc);
         float sc, sh;
         epi_channel_affine(d.epi, co, sc, sh);
-        o[co] = epi_finish(d.epi, acc * sc + sh, m, n, co, Cout);
+        Act<T>::st1(d.out, o0 + co, epi_finish<T>(d.epi, acc * sc + sh, m, n, co, Cout));
     }
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci) {
@@ -104,20 +106,20 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
         ep.bias = nullptr;
         float sc, sh;
         epi_channel_affine(ep, co, sc, sh);
-        o[co] = epi_finish(d.epi, mx * sc + sh, m, n, co, Cout);
+        Act<T>::st1(d.out, o0 + co, epi_finish<T>(d.epi, mx * sc + sh, m, n, co, Cout));
     }
 }
 
 // Weight/bias gradient of the above: dW[co][e] = sum_pix g[pix][co] * patch[pix][e] over the block's
 // pixel slab (Cc <= 16).
 struct FirstDownWgradDesc {
-    const float *x;
+    const void *x;       // storage type T
     long long sn, sc, sh, sw;
-    const float *g;      // [M][g_C] gradient wrt the pre-activation concat, conv channels first
+    const void *g;       // [M][g_C] gradient wrt the pre-activation concat, conv channels first (T)
     float *partial;      // [nsplit][Cc*27 + Cc]
     int N, H, W, Cc, g_C;
     int split_pixels;
-    unsigned x_bytes;    // extent of x covered by its strides
+    unsigned x_elems;    // extent of x covered by its strides
 };
 
 // MFMA 16x16x4: row = conv channel co, contraction = 4 consecutive output pixels, column = patch
@@ -125,6 +127,7 @@ struct FirstDownWgradDesc {
 // g[pix g][co = i] and the two patch elements e = i, 16 + i of pixel g straight from global memory
 // (buffer loads: out-of-image taps, pixels beyond the slab and padding columns read zero).  Each
 // wave covers a quarter of the block's pixel slab; the four waves are summed through LDS.
+template <typename AT>
 __global__ __launch_bounds__(256) void first_down_wgrad_kernel(const FirstDownWgradDesc d)
 {
     __shared__ float red[4][16 * 32];
@@ -135,8 +138,8 @@ __global__ __launch_bounds__(256) void first_down_wgrad_kernel(const FirstDownWg
     const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
     unsigned wend = wbeg + wsp;
     if (wend > M) wend = M;
-    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x, d.x_bytes);
-    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, M * d.g_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x, d.x_elems * Act<AT>::B);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, M * d.g_C * Act<AT>::B);
     // this lane's two patch elements: e -> (ci, kh, kw); e = 27 is the bias column, e > 27 padding
     int eci[2], ekh[2], ekw[2];
 #pragma unroll
@@ -155,13 +158,13 @@ __global__ __launch_bounds__(256) void first_down_wgrad_kernel(const FirstDownWg
         const unsigned mm = valid ? m : 0;
         const unsigned n = mm / HWo, rem = mm - n * HWo;
         const unsigned oh = rem / Wo, ow = rem - oh * Wo;
-        f.gv = buf_load1(r_g, (valid && i < d.Cc) ? (mm * d.g_C + i) * 4u : ERF_OOB);
+        f.gv = Act<AT>::load1(r_g, (valid && i < d.Cc) ? (mm * d.g_C + i) : ERF_OOB);
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
             const int ih = 2 * (int)oh - 1 + ekh[T], iw = 2 * (int)ow - 1 + ekw[T];
             const bool ok = valid && 16 * T + i < 27 && ih >= 0 && iw >= 0 && ih < d.H && iw < d.W;
             const long long off = (long long)n * d.sn + eci[T] * d.sc + ih * d.sh + iw * d.sw;
-            f.pv[T] = buf_load1(r_x, ok ? (unsigned)off * 4u : ERF_OOB);
+            f.pv[T] = Act<AT>::load1(r_x, ok ? (unsigned)off : ERF_OOB);
         }
         if (bias_lane) f.pv[1] = valid ? 1.0f : 0.0f;
     };
@@ -218,12 +221,13 @@ __global__ __launch_bounds__(256) void reduce_flat_kernel(const float *partial, 
 // 2x2 stride-2 max-pool of in[N][H][W][C] into channels [out_coff, out_coff+C) of
 // out[N][H/2][W/2][out_C], with the shared epilogue.  One thread per (output pixel, 4 channels).
 struct PoolDesc {
-    const float *in;
-    float *out;
+    const void *in;      // storage type T
+    void *out;
     Epilogue epi;
     int N, H, W, C, out_C, out_coff;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolDesc d)
 {
     const int Ho = d.H / 2, Wo = d.W / 2, C4 = d.C / 4;
@@ -235,11 +239,11 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolDesc d)
     const int n = (int)(m / (Ho * Wo));
     const int rem = (int)(m - (long long)n * Ho * Wo);
     const int oh = rem / Wo, ow = rem - oh * Wo;
-    const float *p = d.in + (((long long)n * d.H + 2 * oh) * d.W + 2 * ow) * d.C + c;
-    const f32x4 v00 = *reinterpret_cast<const f32x4 *>(p);
-    const f32x4 v01 = *reinterpret_cast<const f32x4 *>(p + d.C);
-    const f32x4 v10 = *reinterpret_cast<const f32x4 *>(p + (long long)d.W * d.C);
-    const f32x4 v11 = *reinterpret_cast<const f32x4 *>(p + (long long)d.W * d.C + d.C);
+    const long long p = (((long long)n * d.H + 2 * oh) * d.W + 2 * ow) * d.C + c;
+    const f32x4 v00 = Act<T>::ld4(d.in, p);
+    const f32x4 v01 = Act<T>::ld4(d.in, p + d.C);
+    const f32x4 v10 = Act<T>::ld4(d.in, p + (long long)d.W * d.C);
+    const f32x4 v11 = Act<T>::ld4(d.in, p + (long long)d.W * d.C + d.C);
     f32x4 o;
     Epilogue ep = d.epi;
     ep.bias = nullptr;
@@ -252,19 +256,20 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const PoolDesc d)
         const int co = d.out_coff + c + e;
         float sc, sh;
         epi_channel_affine(ep, co, sc, sh);
-        o[e] = epi_finish(d.epi, mx * sc + sh, m, n, co, d.out_C);
+        o[e] = epi_finish<T>(d.epi, mx * sc + sh, m, n, co, d.out_C);
     }
-    *reinterpret_cast<f32x4 *>(d.out + m * d.out_C + d.out_coff + c) = o;
+    Act<T>::st4(d.out, m * d.out_C + d.out_coff + c, o);
 }
 
 // Max-pool backward: dx[n][2oh+a][2ow+b][c] = (first maximum of the window in scan order) ?
 // g[n][oh][ow][g_coff+c] : 0.  Writes every element of dx.
 struct PoolBwdDesc {
-    const float *in, *g;
-    float *dx;
+    const void *in, *g;  // storage type T
+    void *dx;
     int N, H, W, C, g_C, g_coff;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdDesc d)
 {
     const int Ho = d.H / 2, Wo = d.W / 2;
@@ -278,17 +283,18 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdDesc d)
     const int oh = rem / Wo, ow = rem - oh * Wo;
     const long long base = (((long long)n * d.H + 2 * oh) * d.W + 2 * ow) * d.C + c;
     const long long o01 = d.C, o10 = (long long)d.W * d.C, o11 = o10 + d.C;
-    const float v00 = d.in[base], v01 = d.in[base + o01], v10 = d.in[base + o10], v11 = d.in[base + o11];
+    const float v00 = Act<T>::ld1(d.in, base), v01 = Act<T>::ld1(d.in, base + o01), v10 = Act<T>::ld1(d.in, base + o10),
+                v11 = Act<T>::ld1(d.in, base + o11);
     int best = 0;
     float mx = v00;
     if (v01 > mx) { mx = v01; best = 1; }
     if (v10 > mx) { mx = v10; best = 2; }
     if (v11 > mx) { mx = v11; best = 3; }
-    const float gv = d.g[m * d.g_C + d.g_coff + c];
-    d.dx[base] = best == 0 ? gv : 0.0f;
-    d.dx[base + o01] = best == 1 ? gv : 0.0f;
-    d.dx[base + o10] = best == 2 ? gv : 0.0f;
-    d.dx[base + o11] = best == 3 ? gv : 0.0f;
+    const float gv = Act<T>::ld1(d.g, m * d.g_C + d.g_coff + c);
+    Act<T>::st1(d.dx, base, best == 0 ? gv : 0.0f);
+    Act<T>::st1(d.dx, base + o01, best == 1 ? gv : 0.0f);
+    Act<T>::st1(d.dx, base + o10, best == 2 ? gv : 0.0f);
+    Act<T>::st1(d.dx, base + o11, best == 3 ? gv : 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -297,9 +303,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const PoolBwdDesc d)
 // second moment named below).
 // bn_stats_kernel: x [M][C].   bn_bwd_stats_kernel: sum g and sum g*xhat with g = gy*(mask>0)*nscale.
 struct BnStatsDesc {
-    const float *x;        // pre-BN tensor [M][C]
-    const float *gy;       // backward only
-    const float *mask;     // backward only, may be NULL: gy counted where mask > 0
+    const void *x;         // pre-BN tensor [M][C]            (x, gy, mask: storage type T)
+    const void *gy;        // backward only
+    const void *mask;      // backward only, may be NULL: gy counted where mask > 0
     const float *nscale;   // backward only, may be NULL: [N][C]
     const float *mean, *invstd;
     double *sums;          // [2C], zeroed by the caller
@@ -307,7 +313,7 @@ struct BnStatsDesc {
     int C, pix_per_image, rows_per_block;
 };
 
-template <bool BWD>
+template <bool BWD, typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const BnStatsDesc d)
 {
     __shared__ float red[2][256];
@@ -321,10 +327,10 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const BnStatsDesc d)
         if (r1 > d.M) r1 = d.M;
         const float mean = BWD ? d.mean[c] : 0.0f, inv = BWD ? d.invstd[c] : 0.0f;
         for (long long r = r0 + rr; r < r1; r += tpr) {
-            const float xv = d.x[r * C + c];
+            const float xv = Act<T>::ld1(d.x, r * C + c);
             if (BWD) {
-                float g = d.gy[r * C + c];
-                if (d.mask && !(d.mask[r * C + c] > 0.0f)) g = 0.0f;
+                float g = Act<T>::ld1(d.gy, r * C + c);
+                if (d.mask && !(Act<T>::ld1(d.mask, r * C + c) > 0.0f)) g = 0.0f;
                 if (d.nscale) g *= d.nscale[(r / d.pix_per_image) * C + c];
                 s0 += g;
                 s1 += g * (xv - mean) * inv;
@@ -354,7 +360,7 @@ struct BnStats4Desc {
     double *partial;       // [gridDim.x][2C]
 };
 
-template <bool BWD>
+template <bool BWD, typename T>
 __global__ __launch_bounds__(256) void bn_stats4_kernel(const BnStats4Desc dd)
 {
     const BnStatsDesc &d = dd.s;
@@ -370,11 +376,11 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const BnStats4Desc dd)
             inv = *reinterpret_cast<const f32x4 *>(d.invstd + 4 * cq);
         }
         for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
-            const f32x4 xv = *reinterpret_cast<const f32x4 *>(d.x + r * C + 4 * cq);
+            const f32x4 xv = Act<T>::ld4(d.x, r * C + 4 * cq);
             if (BWD) {
-                f32x4 g = *reinterpret_cast<const f32x4 *>(d.gy + r * C + 4 * cq);
+                f32x4 g = Act<T>::ld4(d.gy, r * C + 4 * cq);
                 if (d.mask) {
-                    const f32x4 mk = *reinterpret_cast<const f32x4 *>(d.mask + r * C + 4 * cq);
+                    const f32x4 mk = Act<T>::ld4(d.mask, r * C + 4 * cq);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = mk[e] > 0.0f ? g[e] : 0.0f;
                 }
@@ -459,13 +465,14 @@ __global__ void bn_eval_prepare_kernel(const float *run_mean, const float *run_v
 // Element-wise pass over [M][C] (float4): out = epilogue(in).  Used for BatchNorm apply (+dropout
 // scale, residual, ReLU) and for gradient masking.
 struct EltDesc {
-    const float *in;
-    float *out;
+    const void *in;        // storage type T
+    void *out;
     Epilogue epi;
     long long M;
     int C, pix_per_image;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void elt_kernel(const EltDesc d)
 {
     const int C4 = d.C / 4;
@@ -475,21 +482,22 @@ __global__ __launch_bounds__(256) void elt_kernel(const EltDesc d)
         const int c = (int)(idx % C4) * 4;
         const long long m = idx / C4;
         const int n = (int)(m / d.pix_per_image);
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(d.in + m * d.C + c);
+        const f32x4 v = Act<T>::ld4(d.in, m * d.C + c);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float sc, sh;
             epi_channel_affine(d.epi, c + e, sc, sh);
-            o[e] = epi_finish(d.epi, v[e] * sc + sh, m, n, c + e, d.C);
+            o[e] = epi_finish<T>(d.epi, v[e] * sc + sh, m, n, c + e, d.C);
         }
-        *reinterpret_cast<f32x4 *>(d.out + m * d.C + c) = o;
+        Act<T>::st4(d.out, m * d.C + c, o);
     }
 }
 
 // The same pass for channel counts whose float4 columns divide the block (256 % (C/4) == 0) and
 // 16-byte addressable optional tensors: a thread keeps one channel quad, so the per-channel affine
 // is formed once, rows advance without any division, and every tensor moves as 16-byte accesses.
+template <typename T>
 __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
 {
     const int C = d.C, C4 = C / 4, RP = 256 / C4;
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
     const bool has_res = ep.res != nullptr, has_mask = ep.mask != nullptr, has_ns = ep.nscale != nullptr;
     const bool relu = ep.relu != 0;
     for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(d.in + r * C + c);
+        const f32x4 v = Act<T>::ld4(d.in, r * C + c);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v[e] * sc[e] + sh[e];
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
             for (int e = 0; e < 4; ++e) o[e] *= ns[e];
         }
         if (has_res) {
-            const f32x4 rs = *reinterpret_cast<const f32x4 *>(ep.res + r * ep.res_C + ep.res_coff + c);
+            const f32x4 rs = Act<T>::ld4(ep.res, r * ep.res_C + ep.res_coff + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += rs[e];
         }
@@ -520,11 +528,11 @@ __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
             for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.0f);
         }
         if (has_mask) {
-            const f32x4 mk = *reinterpret_cast<const f32x4 *>(ep.mask + r * ep.mask_C + ep.mask_coff + c);
+            const f32x4 mk = Act<T>::ld4(ep.mask, r * ep.mask_C + ep.mask_coff + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = mk[e] > 0.0f ? o[e] : 0.0f;
         }
-        *reinterpret_cast<f32x4 *>(d.out + r * C + c) = o;
+        Act<T>::st4(d.out, r * C + c, o);
     }
 }
 
@@ -532,13 +540,16 @@ __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
 //   train: dx = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M);  eval: dx = gamma*invstd*g.
 // dgamma = sum_gx, dbeta = sum_g are written by block 0.
 struct BnBwdDesc {
-    const float *x, *gy, *mask, *nscale, *gamma, *mean, *invstd;
+    const void *x, *gy, *mask;      // storage type T
+    const float *nscale, *gamma, *mean, *invstd;
     const double *sums;
-    float *dx, *dgamma, *dbeta;
+    void *dx;                       // storage type T
+    float *dgamma, *dbeta;
     long long M;
     int C, pix_per_image, training;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdDesc d)
 {
     const int C4 = d.C / 4;
@@ -553,14 +564,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdDesc d)
          idx += (long long)gridDim.x * 256) {
         const int c = (int)(idx % C4) * 4;
         const long long m = idx / C4;
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(d.x + m * d.C + c);
-        f32x4 g = *reinterpret_cast<const f32x4 *>(d.gy + m * d.C + c);
+        const f32x4 xv = Act<T>::ld4(d.x, m * d.C + c);
+        f32x4 g = Act<T>::ld4(d.gy, m * d.C + c);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int ch = c + e;
             float gv = g[e];
-            if (d.mask && !(d.mask[m * d.C + ch] > 0.0f)) gv = 0.0f;
+            if (d.mask && !(Act<T>::ld1(d.mask, m * d.C + ch) > 0.0f)) gv = 0.0f;
             if (d.nscale) gv *= d.nscale[(m / d.pix_per_image) * d.C + ch];
             const float gi = (d.gamma ? d.gamma[ch] : 1.0f) * d.invstd[ch];
             if (d.training) {
@@ -571,12 +582,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdDesc d)
                 o[e] = gi * gv;
             }
         }
-        *reinterpret_cast<f32x4 *>(d.dx + m * d.C + c) = o;
+        Act<T>::st4(d.dx, m * d.C + c, o);
     }
 }
 
 // Row-structured variant (256 % (C/4) == 0, 16-byte aligned tensors): per-channel constants once
 // per thread, no divisions, 16-byte accesses for the mask and the dropout factors as well.
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const BnBwdDesc d)
 {
     const int C = d.C, C4 = C / 4, RP = 256 / C4;
@@ -599,10 +611,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const BnBwdDesc 
     }
     const bool has_mask = d.mask != nullptr, has_ns = d.nscale != nullptr, training = d.training != 0;
     for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(d.x + r * C + c);
-        f32x4 g = *reinterpret_cast<const f32x4 *>(d.gy + r * C + c);
+        const f32x4 xv = Act<T>::ld4(d.x, r * C + c);
+        f32x4 g = Act<T>::ld4(d.gy, r * C + c);
         if (has_mask) {
-            const f32x4 mk = *reinterpret_cast<const f32x4 *>(d.mask + r * C + c);
+            const f32x4 mk = Act<T>::ld4(d.mask, r * C + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = mk[e] > 0.0f ? g[e] : 0.0f;
         }
@@ -621,7 +633,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const BnBwdDesc 
                 o[e] = gi[e] * g[e];
             }
         }
-        *reinterpret_cast<f32x4 *>(d.dx + r * C + c) = o;
+        Act<T>::st4(d.dx, r * C + c, o);
     }
 }
 
@@ -633,12 +645,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const BnBwdDesc 
 #define OC_CIN 16
 #define OC_MAX_NCLS 32
 struct OutConvDesc {
-    const float *x, *w, *b;
-    float *y;
+    const void *x;         // NHWC, storage type T
+    const float *w, *b;
+    void *y;               // NCHW logits, storage type TO
     int N, H, W, ncls;
 };
 
-template <bool SOFTMAX>
+template <bool SOFTMAX, typename T, typename TO>
 __global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
 {
     __shared__ __attribute__((aligned(16))) float ws[OC_MAX_NCLS * 4 * OC_CIN];
@@ -658,7 +671,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
     float xv[OC_CIN];
 #pragma unroll
     for (int q = 0; q < OC_CIN / 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(d.x + m * OC_CIN + q * 4);
+        const f32x4 v = Act<T>::ld4(d.x, m * OC_CIN + q * 4);
         xv[q * 4] = v[0]; xv[q * 4 + 1] = v[1]; xv[q * 4 + 2] = v[2]; xv[q * 4 + 3] = v[3];
     }
     const int Ho = 2 * d.H, Wo = 2 * d.W;
@@ -672,7 +685,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
 #pragma unroll
                 for (int c = 0; c < OC_CIN; ++c) { r0 = fmaf(xv[c], w0[c], r0); r1 = fmaf(xv[c], w1[c], r1); }
                 f32x2 st = {r0, r1};
-                *reinterpret_cast<f32x2 *>(d.y + (((long long)n * d.ncls + o) * Ho + 2 * i + a) * Wo + 2 * j) = st;
+                Act<TO>::st2(d.y, (((long long)n * d.ncls + o) * Ho + 2 * i + a) * Wo + 2 * j, st);
             }
         }
     } else {
@@ -711,7 +724,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
                     r[b] = expf(v - mx[a * 2 + b]) / sum[a * 2 + b];
                 }
                 f32x2 st = {r[0], r[1]};
-                *reinterpret_cast<f32x2 *>(d.y + (((long long)n * d.ncls + o) * Ho + 2 * i + a) * Wo + 2 * j) = st;
+                Act<TO>::st2(d.y, (((long long)n * d.ncls + o) * Ho + 2 * i + a) * Wo + 2 * j, st);
             }
     }
     }
@@ -720,6 +733,7 @@ __global__ __launch_bounds__(256) void outconv_fwd_kernel(const OutConvDesc d)
 // Class index of the largest logit per output position, written as int64 [N][1][2H][2W]: the
 // `outputs.max(1)[1]` of the evaluation scripts without the logits ever reaching memory.  The
 // logits are formed exactly as in outconv_fwd_kernel (same fma order); ties go to the lowest index.
+template <typename T>
 __global__ __launch_bounds__(256) void outconv_argmax_kernel(const OutConvDesc d, long long *labels)
 {
     __shared__ __attribute__((aligned(16))) float ws[OC_MAX_NCLS * 4 * OC_CIN];
@@ -739,7 +753,7 @@ __global__ __launch_bounds__(256) void outconv_argmax_kernel(const OutConvDesc d
     float xv[OC_CIN];
 #pragma unroll
     for (int q = 0; q < OC_CIN / 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(d.x + m * OC_CIN + q * 4);
+        const f32x4 v = Act<T>::ld4(d.x, m * OC_CIN + q * 4);
         xv[q * 4] = v[0]; xv[q * 4 + 1] = v[1]; xv[q * 4 + 2] = v[2]; xv[q * 4 + 3] = v[3];
     }
     float best[4];
@@ -770,12 +784,15 @@ __global__ __launch_bounds__(256) void outconv_argmax_kernel(const OutConvDesc d
 
 // dx[n][i][j][c] = sum_{o,a,b} gy[n][o][2i+a][2j+b] * w[c][o][a][b]   (gy NCHW, dx NHWC)
 struct OutConvBwdDesc {
-    const float *x, *w, *gy;
-    float *dx, *partial;
+    const void *x;         // NHWC, storage type T
+    const float *w, *gy;   // gy: gradient of the fp32 logits, NCHW
+    void *dx;              // NHWC, storage type T
+    float *partial;
     int N, H, W, ncls, split_pixels;
     int mask_dx;
 };
 
+template <typename T>
 __global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc d)
 {
     __shared__ __attribute__((aligned(16))) float ws[OC_MAX_NCLS * 4 * OC_CIN];
@@ -808,11 +825,11 @@ __global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc
     for (int q = 0; q < OC_CIN / 4; ++q) {
         f32x4 v = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
         if (d.mask_dx) {          // gradient handed to a ReLU-ended producer, masked here by x > 0
-            const f32x4 xv = *reinterpret_cast<const f32x4 *>(d.x + m * OC_CIN + q * 4);
+            const f32x4 xv = Act<T>::ld4(d.x, m * OC_CIN + q * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = xv[e] > 0.0f ? v[e] : 0.0f;
         }
-        *reinterpret_cast<f32x4 *>(d.dx + m * OC_CIN + q * 4) = v;
+        Act<T>::st4(d.dx, m * OC_CIN + q * 4, v);
     }
     }
 }
@@ -820,6 +837,7 @@ __global__ __launch_bounds__(256) void outconv_dgrad_kernel(const OutConvBwdDesc
 // dw[c][o][a][b] = sum_pix x[pix][c]*gy[o][pix,a,b]; db[o] = sum gy.  Thread (oab, cq) accumulates
 // 4 input channels for one (o,a,b) over the block's pixel slab from LDS tiles; a 5th "channel
 // group" row carries the bias sum.  Slab layout: [ncls*4][16] then [ncls*4] bias partials.
+template <typename AT>
 __global__ __launch_bounds__(256) void outconv_wgrad_kernel(const OutConvBwdDesc d)
 {
     // MFMA 16x16x4: row = input channel c, contraction = 4 consecutive input pixels, column = (o,a,b)
@@ -836,7 +854,7 @@ __global__ __launch_bounds__(256) void outconv_wgrad_kernel(const OutConvBwdDesc
     const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
     unsigned wend = wbeg + wsp;
     if (wend > M) wend = M;
-    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x, M * OC_CIN * 4u);
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.x, M * OC_CIN * Act<AT>::B);
     const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.gy, M * 4u * d.ncls * 4u);
     // per column tile: this lane's (o, a, b) as an element offset into one image's gy, or padding
     unsigned coff[MAXT];
@@ -857,7 +875,7 @@ __global__ __launch_bounds__(256) void outconv_wgrad_kernel(const OutConvBwdDesc
         const unsigned mm = valid ? m : 0;
         const unsigned n = mm / HW, rem = mm - n * HW;
         const unsigned y = rem / d.W, x = rem - y * d.W;
-        f.xv = buf_load1(r_x, valid ? (mm * OC_CIN + i) * 4u : ERF_OOB);
+        f.xv = Act<AT>::load1(r_x, valid ? (mm * OC_CIN + i) : ERF_OOB);
         const unsigned base = n * d.ncls * Ho * Wo + 2 * y * Wo + 2 * x;
 #pragma unroll
         for (int T = 0; T < MAXT; ++T)

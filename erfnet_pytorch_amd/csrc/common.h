@@ -6,6 +6,36 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// Activation tensors are stored as fp32 or as bf16 (raw 16-bit patterns, bf16_t); arithmetic outside
+// the bf16 MFMA operands is fp32 either way.  Kernels that serve both are templates on the storage
+// type T and go through the helpers below; descriptors carry activation pointers as void*.
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+// round to nearest even; NaN stays NaN (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v)
+{
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    return __builtin_bit_cast(u32x2, o);
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 u)
+{
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, u[0] << 16);
+    v[1] = __builtin_bit_cast(float, u[0] & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, u[1] << 16);
+    v[3] = __builtin_bit_cast(float, u[1] & 0xffff0000u);
+    return v;
+}
 
 #define ERF_MAX_TAPS 9
 #define ERF_MAX_GROUPS 4
@@ -27,9 +57,9 @@ struct Epilogue {
     const float *bias;
     BnAffine bn;
     const float *nscale;   // [N][Nout]  (Dropout2d keep/scale factors)
-    const float *res;
+    const void *res;       // activation tensors (storage type of the kernel)
     int res_C, res_coff;
-    const float *mask;
+    const void *mask;
     int mask_C, mask_coff;
     int relu;
 };
@@ -43,8 +73,10 @@ struct Epilogue {
 //   tap groups    : blockIdx.z = g selects taps [gtap0[g], gtap0[g]+gntaps[g]) — the output-parity
 //                   classes of a stride-2 transposed convolution; ordinary convolutions have 1 group.
 struct IgemmDesc {
-    const float *in, *w, *wp;
-    float *out;
+    const void *in;         // activations (storage type of the kernel)
+    const float *w;         // weights in torch's layout, always fp32
+    const void *wp;         // packed weights: fp32, or bf16 for the bf16 kernels
+    void *out;
     Epilogue epi;
     int N, GH, GW;
     int in_H, in_W, in_C, in_coff, K;
@@ -53,6 +85,7 @@ struct IgemmDesc {
     int wsk, wsn;
     int ngroups, gtap0[ERF_MAX_GROUPS], gntaps[ERF_MAX_GROUPS], goa[ERF_MAX_GROUPS], gob[ERF_MAX_GROUPS];
     int out_H, out_W, out_C, out_coff, Nout, os;
+    int dt;            // storage type of the activation tensors: 0 = fp32, 1 = bf16
     int Npad;          // padded column count of wp (multiple of the block's BN)
     int cfg;           // host side: tile configuration chosen by plan_igemm
     int vec_ok;        // in_C, in_coff, K all multiples of 4 and `in` 16-byte aligned
@@ -62,7 +95,7 @@ struct IgemmDesc {
 // `nsplit` slabs: partial[s][t][k][j] (k < K, j < Nout), plus bias row partial_b[s][j].
 //   g pixel = (gi*os + toa[t], gj*os + tob[t]) of g[N][g_H][g_W][g_C] (+g_coff).
 struct WgradDesc {
-    const float *in, *g;
+    const void *in, *g;     // activations / gradients (storage type of the kernel)
     float *partial;     // [nsplit][ntaps*K*Nout + Nout]
     int N, GH, GW;
     int in_H, in_W, in_C, in_coff, K;
@@ -72,6 +105,7 @@ struct WgradDesc {
     int nsplit, split_pixels;   // pixels per slab (multiple of 32)
     int itiles, jtiles;
     int vec_ok;
+    int dt;            // storage type of in / g: 0 = fp32, 1 = bf16
 };
 
 // Global loads go through buffer descriptors: a lane whose operand is masked (tap outside the
@@ -81,7 +115,7 @@ struct WgradDesc {
 // the compiler wait for each load separately.  Descriptors cover at most 2^31 bytes (host check).
 #define ERF_OOB 0x80000000u
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, unsigned bytes)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes)
 {
     // readfirstlane makes the descriptor words provably wave-uniform; otherwise the compiler
     // wraps every buffer access in a per-lane "waterfall" loop
@@ -94,7 +128,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, unsi
 }
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off)
 {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
     return __builtin_bit_cast(f32x4, v);
 }
@@ -104,13 +137,60 @@ __device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned by
 }
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v)
 {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, 0);
 }
 __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v)
 {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)byte_off, 0, 0);
 }
+
+// Storage-type view of the same accesses: offsets are in ELEMENTS (bit 31 = out of range), a quad is
+// four consecutive channels.
+template <typename T> struct Act;
+template <> struct Act<float> {
+    static constexpr unsigned B = 4;
+    static __device__ __forceinline__ f32x4 load4(__amdgpu_buffer_rsrc_t r, unsigned e) { return buf_load4(r, (e << 2) | (e & ERF_OOB)); }
+    static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned e) { return buf_load1(r, (e << 2) | (e & ERF_OOB)); }
+    static __device__ __forceinline__ void store4(__amdgpu_buffer_rsrc_t r, unsigned e, f32x4 v) { buf_store4(r, (e << 2) | (e & ERF_OOB), v); }
+    static __device__ __forceinline__ void store1(__amdgpu_buffer_rsrc_t r, unsigned e, float v) { buf_store1(r, (e << 2) | (e & ERF_OOB), v); }
+    static __device__ __forceinline__ f32x4 ld4(const void *p, long long e) { return *reinterpret_cast<const f32x4 *>((const float *)p + e); }
+    static __device__ __forceinline__ float ld1(const void *p, long long e) { return ((const float *)p)[e]; }
+    static __device__ __forceinline__ void st4(void *p, long long e, f32x4 v) { *reinterpret_cast<f32x4 *>((float *)p + e) = v; }
+    static __device__ __forceinline__ void st1(void *p, long long e, float v) { ((float *)p)[e] = v; }
+    static __device__ __forceinline__ void st2(void *p, long long e, f32x2 v) { *reinterpret_cast<f32x2 *>((float *)p + e) = v; }
+};
+template <> struct Act<bf16_t> {
+    static constexpr unsigned B = 2;
+    static __device__ __forceinline__ f32x4 load4(__amdgpu_buffer_rsrc_t r, unsigned e)
+    {
+        return unpack_bf16x4(__builtin_amdgcn_raw_buffer_load_b64(r, (int)((e << 1) | (e & ERF_OOB)), 0, 0));
+    }
+    static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned e)
+    {
+        return bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, (int)((e << 1) | (e & ERF_OOB)), 0, 0));
+    }
+    static __device__ __forceinline__ void store4(__amdgpu_buffer_rsrc_t r, unsigned e, f32x4 v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), r, (int)((e << 1) | (e & ERF_OOB)), 0, 0);
+    }
+    static __device__ __forceinline__ void store1(__amdgpu_buffer_rsrc_t r, unsigned e, float v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16(v), r, (int)((e << 1) | (e & ERF_OOB)), 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 ld4(const void *p, long long e)
+    {
+        return unpack_bf16x4(*reinterpret_cast<const u32x2 *>((const bf16_t *)p + e));
+    }
+    static __device__ __forceinline__ float ld1(const void *p, long long e) { return bf16_to_f32(((const bf16_t *)p)[e]); }
+    static __device__ __forceinline__ void st4(void *p, long long e, f32x4 v) { *reinterpret_cast<u32x2 *>((bf16_t *)p + e) = pack_bf16x4(v); }
+    static __device__ __forceinline__ void st1(void *p, long long e, float v) { ((bf16_t *)p)[e] = f32_to_bf16(v); }
+    static __device__ __forceinline__ void st2(void *p, long long e, f32x2 v)
+    {
+        bf16x2 o;
+        o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1];
+        *reinterpret_cast<unsigned *>((bf16_t *)p + e) = __builtin_bit_cast(unsigned, o);
+    }
+};
 
 // Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2.
 // Tiles that share input rows (the taps of a convolution reach d rows up and down) should meet in
@@ -150,12 +230,13 @@ __device__ __forceinline__ void epi_channel_affine(const Epilogue &e, int c, flo
     }
 }
 
+template <typename T = float>
 __device__ __forceinline__ float epi_finish(const Epilogue &e, float v, long long pix, int n, int c,
                                             int Nout)
 {
     if (e.nscale) v *= e.nscale[(long long)n * Nout + c];
-    if (e.res) v += e.res[pix * e.res_C + e.res_coff + c];
+    if (e.res) v += Act<T>::ld1(e.res, pix * e.res_C + e.res_coff + c);
     if (e.relu) v = fmaxf(v, 0.0f);
-    if (e.mask) v = e.mask[pix * e.mask_C + e.mask_coff + c] > 0.0f ? v : 0.0f;
+    if (e.mask) v = Act<T>::ld1(e.mask, pix * e.mask_C + e.mask_coff + c) > 0.0f ? v : 0.0f;
     return v;
 }

@@ -6,6 +6,7 @@
 #include "stream16.h"
 #include "sampler16.h"
 #include "pair.h"
+#include "line_bf16.h"
 #include "wgrad_line.h"
 #include "loss_kernels.h"
 #include "metric_kernels.h"
@@ -56,6 +57,14 @@ int fail(const char *fmt, ...)
     return 1;
 }
 
+// Launch a kernel template instantiated for the storage type of the activations: inside the
+// argument, T is float (dt == 0) or bf16_t (dt != 0).
+#define BY_DT(dt, ...)                                                                             \
+    do {                                                                                           \
+        if (dt) { using T = bf16_t; __VA_ARGS__; }                                                 \
+        else { using T = float; __VA_ARGS__; }                                                     \
+    } while (0)
+
 #define CHECK_LAUNCH(name)                                                                         \
     do {                                                                                           \
         hipError_t e_ = hipGetLastError();                                                         \
@@ -94,6 +103,125 @@ BnAffine bn_saved_affine(const erf_bn_t *bn)
 inline int bn_mode(const erf_bn_t *bn) { return bn ? bn->mode : 0; }
 
 bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// ------------------------------------------------------------------ bf16 line kernel (line_bf16.h)
+int cu_count()
+{
+    static std::atomic<int> n{0};
+    int v = n.load(std::memory_order_relaxed);
+    if (v <= 0) {
+        int dev = 0;
+        v = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int c = 0;
+            if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) v = c;
+        }
+        n.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+// Block tile (pixels of a line) of the bf16 line kernel for NC channels and lines of L pixels;
+// 0 = no kernel.  A pair needs the whole line in one tile; a single convolution may cut the line
+// into segments.
+int line_tile_bf16(int NC, int L, bool pair)
+{
+    if (NC == 128) {
+        if (L <= 32) return 32;
+        if (L <= 64) return 64;
+        if (L <= 128) return 128;
+        return pair ? 0 : 128;
+    }
+    if (NC == 64) {
+        if (L <= 64) return 64;
+        if (L <= 128) return 128;
+        if (L <= 256) return 256;
+        return pair ? 0 : 256;
+    }
+    return 0;
+}
+
+size_t line_packed_elems(int NC) { return (size_t)3 * NC * NC; }
+
+void line_pack_desc(LinePackDesc &k, const float *w, bf16_t *wp, int NC, int wsk, int wsn, const int *woff)
+{
+    memset(&k, 0, sizeof(k));
+    k.w = w; k.wp = wp; k.NC = NC; k.wsk = wsk; k.wsn = wsn;
+    for (int t = 0; t < 3; ++t) k.woff[t] = woff[t];
+}
+
+int launch_line_pack(const LinePackDesc *pks, int n, hipStream_t st)
+{
+    for (int first = 0; first < n; first += ERF_LINE_PACK_BATCH) {
+        const int cnt = n - first < ERF_LINE_PACK_BATCH ? n - first : ERF_LINE_PACK_BATCH;
+        LinePackBatch b;
+        memset(&b, 0, sizeof(b));
+        int most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            b.p[i] = pks[first + i];
+            most = b.p[i].NC > most ? b.p[i].NC : most;
+        }
+        if (!most) continue;
+        line_pack_kernel<<<dim3((unsigned)(3 * most * most / 256 / 4), cnt, 1), 256, 0, st>>>(b);
+        CHECK_LAUNCH("line_pack_kernel");
+    }
+    return 0;
+}
+
+int run_line(const LineDesc &ld, int NC, int BM, bool pair, hipStream_t st)
+{
+    const int ntiles = ld.nlines * ld.segs;
+    if (ntiles <= 0) return 0;
+    const int cus = cu_count();
+    const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+#define LINE_CASE(nc, bm)                                                                           \
+    if (NC == nc && BM == bm) {                                                                     \
+        if (pair) line_bf16_kernel<nc, bm, true><<<grid, 256, 0, st>>>(ld);                        \
+        else line_bf16_kernel<nc, bm, false><<<grid, 256, 0, st>>>(ld);                            \
+        CHECK_LAUNCH("line_bf16_kernel");                                                           \
+        return 0;                                                                                   \
+    }
+    LINE_CASE(128, 32) LINE_CASE(128, 64) LINE_CASE(128, 128)
+    LINE_CASE(64, 64) LINE_CASE(64, 128) LINE_CASE(64, 256)
+#undef LINE_CASE
+    return fail("bf16 line kernel: no variant for %d channels, tile %d", NC, BM);
+}
+
+// A 3-tap 1-D convolution described as an implicit GEMM -> geometry of the line kernel.  The taps
+// run across the lines: a convolution along W takes image columns as lines, one along H image rows.
+// Returns false when the convolution does not fit the kernel.
+bool line_geometry(const IgemmDesc &d, LineDesc &ld)
+{
+    const int NC = d.K;
+    if (NC != 64 && NC != 128) return false;
+    if (d.Nout != NC || d.in_C != NC || d.out_C != NC || d.in_coff || d.out_coff) return false;
+    if (d.ss != 1 || d.os != 1 || d.ngroups != 1 || d.gtap0[0] != 0 || d.gntaps[0] != 3) return false;
+    if (d.goa[0] || d.gob[0] || d.epi.nscale) return false;
+    if (d.in_H != d.GH || d.in_W != d.GW || d.out_H != d.GH || d.out_W != d.GW) return false;
+    if (!aligned16(d.in) || !aligned16(d.out) || d.in == d.out) return false;
+    const long long P = (long long)d.N * d.GH * d.GW;
+    if (P * NC >= (1LL << 31)) return false;
+    if (d.epi.res && (d.epi.res_C != NC || d.epi.res_coff || !aligned16(d.epi.res))) return false;
+    if (d.epi.mask && (d.epi.mask_C != NC || d.epi.mask_coff || !aligned16(d.epi.mask))) return false;
+    if (d.tdh[1] || d.tdw[1]) return false;                 // the centre tap stays on the line
+    bool along_w = true, along_h = true;
+    for (int t = 0; t < 3; ++t) { along_w = along_w && d.tdh[t] == 0; along_h = along_h && d.tdw[t] == 0; }
+    if (!along_w && !along_h) return false;
+    memset(&ld, 0, sizeof(ld));
+    ld.in = (const bf16_t *)d.in; ld.out = (bf16_t *)d.out;
+    ld.epi1 = d.epi; ld.epi2 = kNoEpi;
+    ld.N = d.N; ld.img_pixels = d.GH * d.GW;
+    if (along_w) {
+        ld.lines_per_img = d.GW; ld.L = d.GH; ld.pstride = d.GW; ld.qstride = 1;
+        for (int t = 0; t < 3; ++t) ld.s1[t] = d.tdw[t];
+    } else {
+        ld.lines_per_img = d.GH; ld.L = d.GW; ld.pstride = 1; ld.qstride = d.GW;
+        for (int t = 0; t < 3; ++t) ld.s1[t] = d.tdh[t];
+    }
+    ld.nlines = d.N * ld.lines_per_img;
+    return true;
+}
+const int kCfgLine = 101;
 
 // ---------------------------------------------------------------------------------- igemm launch
 // Tile configurations <WM, WN, GM, GN>: block tile BM = GM*WM*32 pixels x BN = GN*WN*32 channels.
@@ -174,6 +302,21 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
             return fail("igemm: tensors of 2 GiB or more are not supported");
     }
     d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && aligned16(d.in)) ? 1 : 0;
+    if (d.dt) {          // bf16: the 64 / 128-channel 1-D convolutions take the line kernel
+        LineDesc ld;
+        if (line_geometry(d, ld)) {
+            bf16_t *wp = (bf16_t *)ar.take(line_packed_elems(d.K) * sizeof(bf16_t));
+            if (!wp) return fail("igemm: workspace too small for the weight fragments");
+            d.cfg = kCfgLine;
+            d.Npad = d.Nout;
+            d.wp = wp;
+            memset(&pk, 0, sizeof(pk));
+            pk.w = d.w; pk.K = d.K; pk.Nout = d.Nout; pk.wsk = d.wsk; pk.wsn = d.wsn;
+            for (int t = 0; t < 3; ++t) pk.woff[t] = d.woff[t];
+            pk.line = 1; pk.lwp = wp;
+            return 0;
+        }
+    }
     if (stream16_ok(d)) {          // 16 -> 16 channels: LDS-free streaming kernel, unpacked weights
         d.cfg = kCfgStream16;
         d.Npad = 16;
@@ -194,6 +337,7 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
     float *wp = ar.floats(n);
     if (!wp) return fail("igemm: workspace too small for the packed weights (%zu floats)", n);
     d.wp = wp;
+    memset(&pk, 0, sizeof(pk));
     pk.w = d.w; pk.wp = wp;
     pk.ntaps = ntaps; pk.K = d.K; pk.Nout = d.Nout; pk.Npad = d.Npad; pk.wsk = d.wsk; pk.wsn = d.wsn;
     pk.kc = KC;
@@ -203,6 +347,16 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
 
 int launch_pack(const PackDesc *pks, int n, hipStream_t st)
 {
+    {   // fragments of the bf16 line kernel
+        LinePackDesc lp[ERF_LINE_PACK_BATCH];
+        int nl = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!pks[i].line) continue;
+            line_pack_desc(lp[nl++], pks[i].w, pks[i].lwp, pks[i].K, pks[i].wsk, pks[i].wsn, pks[i].woff);
+            if (nl == ERF_LINE_PACK_BATCH) { if (launch_line_pack(lp, nl, st)) return 1; nl = 0; }
+        }
+        if (nl && launch_line_pack(lp, nl, st)) return 1;
+    }
     for (int first = 0; first < n; first += ERF_PACK_BATCH) {
         const int cnt = n - first < ERF_PACK_BATCH ? n - first : ERF_PACK_BATCH;
         PackBatch b;
@@ -223,19 +377,28 @@ int launch_pack(const PackDesc *pks, int n, hipStream_t st)
     return 0;
 }
 
-int run_igemm(const IgemmDesc &d, hipStream_t st)
+template <typename T>
+int run_igemm_t(const IgemmDesc &d, hipStream_t st)
 {
     const long long M = (long long)d.N * d.GH * d.GW;
     if (M == 0) return 0;
+    if (d.cfg == kCfgLine) {
+        LineDesc ld;
+        if (!line_geometry(d, ld)) return fail("igemm: line plan without line geometry");
+        ld.wp1 = (const bf16_t *)d.wp;
+        const int BM = line_tile_bf16(d.K, ld.L, false);
+        ld.segs = (ld.L + BM - 1) / BM;
+        return run_line(ld, d.K, BM, false, st);
+    }
     if (d.cfg == kCfgStream16) {
         // tile groups per wave: the per-wave set-up (descriptors, weights, coordinates) is paid once,
         // as long as about 12 waves per CU remain (ERFNET_CONV16_G overrides, experiments)
         static int forced = -1;
         if (forced < 0) { const char *e = getenv("ERFNET_CONV16_G"); forced = e ? atoi(e) : 0; }
         const int grp = forced ? forced : (M >= 3072LL * 256 ? 4 : (M >= 3072LL * 128 ? 2 : 1));
-        if (grp >= 4) conv16_kernel<3, 4, 4><<<(unsigned)((M + 1023) / 1024), 256, 0, st>>>(d);
-        else if (grp >= 2) conv16_kernel<3, 4, 2><<<(unsigned)((M + 511) / 512), 256, 0, st>>>(d);
-        else conv16_kernel<3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
+        if (grp >= 4) conv16_kernel<T, 3, 4, 4><<<(unsigned)((M + 1023) / 1024), 256, 0, st>>>(d);
+        else if (grp >= 2) conv16_kernel<T, 3, 4, 2><<<(unsigned)((M + 511) / 512), 256, 0, st>>>(d);
+        else conv16_kernel<T, 3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
         CHECK_LAUNCH("conv16_kernel");
         return 0;
     }
@@ -243,21 +406,25 @@ int run_igemm(const IgemmDesc &d, hipStream_t st)
     dim3 grid((unsigned)((M + c.bm - 1) / c.bm), d.Npad / c.bn, d.ngroups);
 #define IG_LAUNCH(KC, MW, MW64)                                                                     \
     switch (d.cfg) {                                                                               \
-    case 0: igemm_f32_kernel<2, 2, 2, 2, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
-    case 1: igemm_f32_kernel<3, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
-    case 2: igemm_f32_kernel<2, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
-    case 3: igemm_f32_kernel<1, 1, 1, 4, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
-    case 4: igemm_f32_kernel<1, 2, 4, 1, KC, MW64, true><<<grid, 256, 0, st>>>(d); break;         \
-    case 5: igemm_f32_kernel<1, 1, 2, 2, KC, MW64, true><<<grid, 256, 0, st>>>(d); break;         \
-    case 6: igemm_f32_kernel<2, 1, 4, 1, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
-    case 7: igemm_f32_kernel<1, 1, 4, 1, KC, MW, true><<<grid, 256, 0, st>>>(d); break;           \
-    default: igemm_f32_kernel<1, 1, 4, 1, KC, MW, false><<<grid, 256, 0, st>>>(d); break;         \
+    case 0: igemm_f32_kernel<2, 2, 2, 2, KC, MW, true, T><<<grid, 256, 0, st>>>(d); break;           \
+    case 1: igemm_f32_kernel<3, 1, 1, 4, KC, MW, true, T><<<grid, 256, 0, st>>>(d); break;           \
+    case 2: igemm_f32_kernel<2, 1, 1, 4, KC, MW, true, T><<<grid, 256, 0, st>>>(d); break;           \
+    case 3: igemm_f32_kernel<1, 1, 1, 4, KC, MW, true, T><<<grid, 256, 0, st>>>(d); break;           \
+    case 4: igemm_f32_kernel<1, 2, 4, 1, KC, MW64, true, T><<<grid, 256, 0, st>>>(d); break;         \
+    case 5: igemm_f32_kernel<1, 1, 2, 2, KC, MW64, true, T><<<grid, 256, 0, st>>>(d); break;         \
+    case 6: igemm_f32_kernel<2, 1, 4, 1, KC, MW, true, T><<<grid, 256, 0, st>>>(d); break;           \
+    case 7: igemm_f32_kernel<1, 1, 4, 1, KC, MW, true, T><<<grid, 256, 0, st>>>(d); break;           \
+    default: igemm_f32_kernel<1, 1, 4, 1, KC, MW, false, T><<<grid, 256, 0, st>>>(d); break;         \
     }
     // minimum blocks per CU (register budget): 64-column tiles keep three blocks resident
     if (igemm_kc(d.K) == 16) { IG_LAUNCH(16, 3, 3) } else { IG_LAUNCH(32, 2, 3) }
 #undef IG_LAUNCH
     CHECK_LAUNCH("igemm_f32_kernel");
     return 0;
+}
+int run_igemm(const IgemmDesc &d, hipStream_t st)
+{
+    return d.dt ? run_igemm_t<bf16_t>(d, st) : run_igemm_t<float>(d, st);
 }
 
 // Single convolution: pack its weights, then run it.
@@ -288,6 +455,15 @@ int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = fa
 {
     if (!ignore_switch && !pair_enabled()) return 0;
     const int NC = a.K;
+    if (a.dt != b.dt) return 0;
+    if (a.dt) {          // bf16: both halves must fit the line kernel, the second running along the first's lines
+        LineDesc la, lb;
+        if (!line_geometry(a, la) || !line_geometry(b, lb) || b.in != a.out || b.K != NC) return 0;
+        if (a.N != b.N || a.GH != b.GH || a.GW != b.GW) return 0;
+        if (a.epi.res) return 0;                            // the residual tile belongs to the second epilogue
+        if (la.pstride == lb.pstride) return 0;             // same axis: not a pair
+        return line_tile_bf16(NC, la.L, true);
+    }
     const IgemmDesc *dd[2] = {&a, &b};
     for (const IgemmDesc *d : dd) {
         if (d->K != NC || d->Nout != NC || d->in_C != NC || d->out_C != NC || d->in_coff || d->out_coff) return 0;
@@ -314,10 +490,42 @@ int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = fa
 
 // Reserve and describe the packed weights (16 channels per K-step) and fill the kernel descriptor.
 // keep_mid = false drops the store of the intermediate tensor.
-int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, PackDesc pk[2], PairDesc &pd)
+// A fused pair as planned: the fp32 kernel's descriptor, or the bf16 line kernel's.
+struct FusedPair {
+    int dt;
+    PairDesc pd;
+    LineDesc ld;
+};
+
+int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, PackDesc pk[2], FusedPair &fp)
 {
     const int NC = a.K;
     const IgemmDesc *dd[2] = {&a, &b};
+    fp.dt = a.dt;
+    if (b.out == a.in || (keep_mid && a.out == a.in))
+        return fail("conv pair: the output must not alias the input (other blocks still read it)");
+    if (a.dt) {
+        LineDesc &ld = fp.ld, lb;
+        if (!line_geometry(a, ld) || !line_geometry(b, lb)) return fail("conv pair (bf16): geometry");
+        bf16_t *wp = (bf16_t *)ar.take(2 * line_packed_elems(NC) * sizeof(bf16_t));
+        if (!wp) return fail("conv pair: workspace too small for the weight fragments");
+        for (int i = 0; i < 2; ++i) {
+            PackDesc &k = pk[i];
+            memset(&k, 0, sizeof(k));
+            k.w = dd[i]->w; k.K = NC; k.Nout = NC; k.wsk = dd[i]->wsk; k.wsn = dd[i]->wsn;
+            for (int t = 0; t < 3; ++t) k.woff[t] = dd[i]->woff[t];
+            k.line = 1; k.lwp = wp + i * line_packed_elems(NC);
+        }
+        ld.wp1 = wp; ld.wp2 = wp + line_packed_elems(NC);
+        ld.mid = keep_mid ? (bf16_t *)a.out : nullptr;
+        ld.out = (bf16_t *)b.out;
+        ld.epi2 = b.epi;
+        ld.segs = 1;
+        // the second convolution runs along the line: its tap offsets in line positions
+        for (int t = 0; t < 3; ++t) ld.s2[t] = ld.pstride == 1 ? b.tdw[t] : b.tdh[t];
+        return 0;
+    }
+    PairDesc &pd = fp.pd;
     const float *wp[2];
     for (int i = 0; i < 2; ++i) {
         const size_t n = (size_t)3 * NC * NC;
@@ -330,12 +538,10 @@ int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, 
         k.wsk = dd[i]->wsk; k.wsn = dd[i]->wsn; k.kc = 16;
         for (int t = 0; t < 3; ++t) k.woff[t] = dd[i]->woff[t];
     }
-    if (b.out == a.in || (keep_mid && a.out == a.in))
-        return fail("conv pair: the output must not alias the input (other blocks still read it)");
     memset(&pd, 0, sizeof(pd));
-    pd.in = a.in; pd.wp1 = wp[0]; pd.wp2 = wp[1];
-    pd.mid = keep_mid ? a.out : nullptr;
-    pd.out = b.out;
+    pd.in = (const float *)a.in; pd.wp1 = wp[0]; pd.wp2 = wp[1];
+    pd.mid = keep_mid ? (float *)a.out : nullptr;
+    pd.out = (float *)b.out;
     pd.epi1 = a.epi; pd.epi2 = b.epi;
     pd.N = a.N; pd.img_pixels = a.GH * a.GW;
     const bool columns = a.tdh[0] == 0 && a.tdh[2] == 0;
@@ -350,7 +556,13 @@ int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, 
     return 0;
 }
 
-int run_pair(const PairDesc &pd, int NC, int tile, hipStream_t st)
+int run_pair_f32(const PairDesc &pd, int NC, int tile, hipStream_t st);
+int run_pair(const FusedPair &fp, int NC, int tile, hipStream_t st)
+{
+    if (fp.dt) return run_line(fp.ld, NC, tile, true, st);
+    return run_pair_f32(fp.pd, NC, tile, st);
+}
+int run_pair_f32(const PairDesc &pd, int NC, int tile, hipStream_t st)
 {
     if (pd.nlines == 0) return 0;
     // fewer lines than two per CU: eight waves per block halve a block's own latency
@@ -470,8 +682,8 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     }
     const int max_split = nsplit;
     dim3 grid((unsigned)max_split, jtiles, n);
-    if (NC == 128) wgrad_line_kernel<128, 1, 2, 4, 2, 1><<<grid, 512, 0, st>>>(wb);
-    else wgrad_line_kernel<64, 1, 1, 2, 2, 3><<<grid, 256, 0, st>>>(wb);
+    if (NC == 128) BY_DT(dd[0].dt, (wgrad_line_kernel<128, 1, 2, 4, 2, 1, T><<<grid, 512, 0, st>>>(wb)));
+    else BY_DT(dd[0].dt, (wgrad_line_kernel<64, 1, 1, 2, 2, 3, T><<<grid, 256, 0, st>>>(wb)));
     CHECK_LAUNCH("wgrad_line_kernel");
     // the slab carries the column sums of G in bias row 0 only
     return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps ? 1u : 0u, st);
@@ -512,7 +724,7 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
             e.split_pixels = (int)sp;
             e.partial = ar.floats(slab * nsplit);
             if (!e.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
-            wgrad16_kernel<3, NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e);
+            BY_DT(d.dt, (wgrad16_kernel<T, 3, NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e)));
             CHECK_LAUNCH("wgrad16_kernel");
         }
         return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);
@@ -564,14 +776,14 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
     }
     dim3 grid((unsigned)nsplit, tiles, n);
     switch (cfg) {
-    case 0: wgrad_f32_kernel<2, 2, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
-    case 1: wgrad_f32_kernel<2, 1, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
-    case 2: wgrad_f32_kernel<1, 2, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
-    case 3: wgrad_f32_kernel<1, 1, 2, 2, true><<<grid, 256, 0, st>>>(wb); break;
-    case 4: wgrad_f32_kernel<1, 1, 1, 2, true, 128><<<grid, 128, 0, st>>>(wb); break;
-    case 5: wgrad_f32_kernel<1, 1, 2, 1, true, 128><<<grid, 128, 0, st>>>(wb); break;
-    case 6: wgrad_f32_kernel<1, 1, 1, 1, true, 64><<<grid, 64, 0, st>>>(wb); break;
-    default: wgrad_f32_kernel<1, 1, 1, 1, false, 64><<<grid, 64, 0, st>>>(wb); break;
+    case 0: BY_DT(d.dt, (wgrad_f32_kernel<2, 2, 2, 2, true, 32, T><<<grid, 256, 0, st>>>(wb))); break;
+    case 1: BY_DT(d.dt, (wgrad_f32_kernel<2, 1, 2, 2, true, 32, T><<<grid, 256, 0, st>>>(wb))); break;
+    case 2: BY_DT(d.dt, (wgrad_f32_kernel<1, 2, 2, 2, true, 32, T><<<grid, 256, 0, st>>>(wb))); break;
+    case 3: BY_DT(d.dt, (wgrad_f32_kernel<1, 1, 2, 2, true, 32, T><<<grid, 256, 0, st>>>(wb))); break;
+    case 4: BY_DT(d.dt, (wgrad_f32_kernel<1, 1, 1, 2, true, 128, T><<<grid, 128, 0, st>>>(wb))); break;
+    case 5: BY_DT(d.dt, (wgrad_f32_kernel<1, 1, 2, 1, true, 128, T><<<grid, 128, 0, st>>>(wb))); break;
+    case 6: BY_DT(d.dt, (wgrad_f32_kernel<1, 1, 1, 1, true, 64, T><<<grid, 64, 0, st>>>(wb))); break;
+    default: BY_DT(d.dt, (wgrad_f32_kernel<1, 1, 1, 1, false, 64, T><<<grid, 64, 0, st>>>(wb))); break;
     }
     CHECK_LAUNCH("wgrad_f32_kernel");
     return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);
@@ -617,10 +829,10 @@ int launch_up16_fwd(const IgemmDesc &d, hipStream_t st)
     long long blocks = (M + 63) / 64;             // one 16-position tile per wave at least
     if (blocks > 768) blocks = 768;               // three resident blocks per CU share the weight fill
     switch (d.K / 16) {
-    case 1: up16_fwd_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(d); break;
-    case 2: up16_fwd_kernel<2><<<(unsigned)blocks, 256, 0, st>>>(d); break;
-    case 3: up16_fwd_kernel<3><<<(unsigned)blocks, 256, 0, st>>>(d); break;
-    default: up16_fwd_kernel<4><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+    case 1: BY_DT(d.dt, (up16_fwd_kernel<T, 1><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
+    case 2: BY_DT(d.dt, (up16_fwd_kernel<T, 2><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
+    case 3: BY_DT(d.dt, (up16_fwd_kernel<T, 3><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
+    default: BY_DT(d.dt, (up16_fwd_kernel<T, 4><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
     }
     CHECK_LAUNCH("up16_fwd_kernel");
     return 0;
@@ -646,7 +858,7 @@ int launch_up16_wgrad(WgradDesc &d, float *dw, float *db, int wsk, int wsn, int 
     d.partial = ar.floats(slab * nsplit);
     if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
     // one 16-channel quad of the coarse side per block (blockIdx.y)
-    up16_wgrad_kernel<1><<<dim3((unsigned)nsplit, KQ, 1), 256, 0, st>>>(d);
+    BY_DT(d.dt, (up16_wgrad_kernel<T, 1><<<dim3((unsigned)nsplit, KQ, 1), 256, 0, st>>>(d)));
     CHECK_LAUNCH("up16_wgrad_kernel");
     ReduceBatch rb;
     memset(&rb, 0, sizeof(rb));
@@ -669,7 +881,7 @@ unsigned grid_for(long long work_items, int per_block = 256, unsigned cap = 8192
     return (unsigned)g;
 }
 
-int launch_elt(const float *in, float *out, const Epilogue &epi, long long M, int C, int pix_per_image,
+int launch_elt(int dt, const void *in, void *out, const Epilogue &epi, long long M, int C, int pix_per_image,
                hipStream_t st)
 {
     if (C % 4) return fail("element-wise pass needs C %% 4 == 0 (C = %d)", C);
@@ -681,20 +893,20 @@ int launch_elt(const float *in, float *out, const Epilogue &epi, long long M, in
                       (!epi.nscale || aligned16(epi.nscale));
     if (rows) {
         const long long steps = (M * C4 + 255) / 256;
-        elt_rows_kernel<<<(unsigned)(steps < 2048 ? (steps < 1 ? 1 : steps) : 2048), 256, 0, st>>>(e);
+        BY_DT(dt, (elt_rows_kernel<T><<<(unsigned)(steps < 2048 ? (steps < 1 ? 1 : steps) : 2048), 256, 0, st>>>(e)));
     } else {
-        elt_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(e);
+        BY_DT(dt, (elt_kernel<T><<<grid_for(M * (C / 4)), 256, 0, st>>>(e)));
     }
     CHECK_LAUNCH("elt_kernel");
     return 0;
 }
 
 // g_out = gy * (mask > 0)
-int launch_mask(const float *gy, const float *mask, float *out, long long M, int C, hipStream_t st)
+int launch_mask(int dt, const void *gy, const void *mask, void *out, long long M, int C, hipStream_t st)
 {
     Epilogue e = kNoEpi;
     e.mask = mask; e.mask_C = C; e.mask_coff = 0;
-    return launch_elt(gy, out, e, M, C, 1, st);
+    return launch_elt(dt, gy, out, e, M, C, 1, st);
 }
 
 // Blocks of the vectorised statistics kernel for M rows of C channels (and the rows of its partial
@@ -713,7 +925,7 @@ size_t bn_scratch_bytes(long long M, int C)
 
 // sums[0..2C) of a statistics pass.  C % 4 == 0 with 16-byte aligned tensors: per-block partial rows
 // and a fixed-order reduction; otherwise the scalar kernel with double atomics.
-int bn_stats_launch(const BnStatsDesc &s, bool bwd, Arena &ar, hipStream_t st)
+int bn_stats_launch(int dt, const BnStatsDesc &s, bool bwd, Arena &ar, hipStream_t st)
 {
     const int C = s.C;
     const bool vec = C % 4 == 0 && aligned16(s.x) && (!bwd || (aligned16(s.gy) && aligned16(s.mean) && aligned16(s.invstd) &&
@@ -723,8 +935,8 @@ int bn_stats_launch(const BnStatsDesc &s, bool bwd, Arena &ar, hipStream_t st)
         double *partial = (double *)ar.take(sizeof(double) * 2 * (size_t)C * G);
         if (!partial) return fail("workspace too small for BatchNorm partial sums");
         BnStats4Desc d4 = {s, partial};
-        if (bwd) bn_stats4_kernel<true><<<G, 256, 0, st>>>(d4);
-        else bn_stats4_kernel<false><<<G, 256, 0, st>>>(d4);
+        if (bwd) BY_DT(dt, (bn_stats4_kernel<true, T><<<G, 256, 0, st>>>(d4)));
+        else BY_DT(dt, (bn_stats4_kernel<false, T><<<G, 256, 0, st>>>(d4)));
         CHECK_LAUNCH("bn_stats4_kernel");
         bn_reduce_kernel<<<(2 * C + 7) / 8, 256, 0, st>>>(partial, s.sums, G, 2 * C);
         CHECK_LAUNCH("bn_reduce_kernel");
@@ -732,14 +944,14 @@ int bn_stats_launch(const BnStatsDesc &s, bool bwd, Arena &ar, hipStream_t st)
     }
     hipMemsetAsync(s.sums, 0, sizeof(double) * 2 * C, st);
     const unsigned grid = (unsigned)((s.M + s.rows_per_block - 1) / s.rows_per_block);
-    if (bwd) bn_stats_kernel<true><<<grid, 256, 0, st>>>(s);
-    else bn_stats_kernel<false><<<grid, 256, 0, st>>>(s);
+    if (bwd) BY_DT(dt, (bn_stats_kernel<true, T><<<grid, 256, 0, st>>>(s)));
+    else BY_DT(dt, (bn_stats_kernel<false, T><<<grid, 256, 0, st>>>(s)));
     CHECK_LAUNCH("bn_stats_kernel");
     return 0;
 }
 
 // Batch statistics of pre [M][C] -> bn->save_mean / save_invstd (+ running stats).
-int bn_train_stats(const erf_bn_t *bn, const float *pre, long long M, int C, Arena &ar, hipStream_t st)
+int bn_train_stats(int dt, const erf_bn_t *bn, const void *pre, long long M, int C, Arena &ar, hipStream_t st)
 {
     if (C > 256) return fail("BatchNorm kernels support C <= 256 (C = %d)", C);
     if (!bn->save_mean || !bn->save_invstd) return fail("BatchNorm train mode needs save_mean/save_invstd");
@@ -747,7 +959,7 @@ int bn_train_stats(const erf_bn_t *bn, const float *pre, long long M, int C, Are
     if (!sums) return fail("workspace too small for BatchNorm sums");
     const int rows = 2048;
     BnStatsDesc s = {pre, nullptr, nullptr, nullptr, nullptr, nullptr, sums, M, C, 1, rows};
-    if (bn_stats_launch(s, false, ar, st)) return 1;
+    if (bn_stats_launch(dt, s, false, ar, st)) return 1;
     bn_finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(sums, bn->save_mean, bn->save_invstd, bn->running_mean,
                                                     bn->running_var, M, C, bn->momentum, bn->eps);
     CHECK_LAUNCH("bn_finalize_kernel");
@@ -755,8 +967,8 @@ int bn_train_stats(const erf_bn_t *bn, const float *pre, long long M, int C, Are
 }
 
 // BatchNorm backward on g = gy*(mask>0)*nscale: dx (may alias nothing), dgamma, dbeta.
-int bn_backward(const erf_bn_t *bn, const float *pre, const float *gy, const float *mask,
-                const float *nscale, float *dx, float *dgamma, float *dbeta, long long M, int C,
+int bn_backward(int dt, const erf_bn_t *bn, const void *pre, const void *gy, const void *mask,
+                const float *nscale, void *dx, float *dgamma, float *dbeta, long long M, int C,
                 int pix_per_image, Arena &ar, hipStream_t st)
 {
     if (C > 256 || C % 4) return fail("BatchNorm kernels support C <= 256, C %% 4 == 0 (C = %d)", C);
@@ -766,16 +978,16 @@ int bn_backward(const erf_bn_t *bn, const float *pre, const float *gy, const flo
     if (!sums) return fail("workspace too small for BatchNorm sums");
     const int rows = 2048;
     BnStatsDesc s = {pre, gy, mask, nscale, bn->save_mean, bn->save_invstd, sums, M, C, pix_per_image, rows};
-    if (bn_stats_launch(s, true, ar, st)) return 1;
+    if (bn_stats_launch(dt, s, true, ar, st)) return 1;
     BnBwdDesc b = {pre, gy, mask, nscale, bn->gamma, bn->save_mean, bn->save_invstd, sums,
                    dx, dgamma, dbeta, M, C, pix_per_image, bn->mode == 2};
     const int C4 = C / 4;
     if (256 % C4 == 0 && aligned16(pre) && aligned16(gy) && aligned16(dx) && (!mask || aligned16(mask)) &&
         (!nscale || aligned16(nscale))) {
         const long long steps = (M * C4 + 255) / 256;
-        bn_bwd_apply_rows_kernel<<<(unsigned)(steps < 2048 ? (steps < 1 ? 1 : steps) : 2048), 256, 0, st>>>(b);
+        BY_DT(dt, (bn_bwd_apply_rows_kernel<T><<<(unsigned)(steps < 2048 ? (steps < 1 ? 1 : steps) : 2048), 256, 0, st>>>(b)));
     } else {
-        bn_bwd_apply_kernel<<<grid_for(M * (C / 4)), 256, 0, st>>>(b);
+        BY_DT(dt, (bn_bwd_apply_kernel<T><<<grid_for(M * (C / 4)), 256, 0, st>>>(b)));
     }
     CHECK_LAUNCH("bn_bwd_apply_kernel");
     return 0;
@@ -801,10 +1013,11 @@ void zero_desc(IgemmDesc &d)
 
 // 1-D convolution of non_bottleneck_1d: along H (axis 0) or W (axis 1), 3 taps, dilation dil.
 // transpose = data gradient (taps mirrored, weight indices swapped).
-void conv1d_desc(IgemmDesc &d, const float *in, const float *w, float *out, int N, int C, int H, int W,
+void conv1d_desc(IgemmDesc &d, int dt, const void *in, const float *w, void *out, int N, int C, int H, int W,
                  int axis, int dil, bool transpose)
 {
     zero_desc(d);
+    d.dt = dt;
     d.in = in; d.w = w; d.out = out;
     d.N = N; d.GH = H; d.GW = W;
     d.in_H = H; d.in_W = W; d.in_C = C; d.in_coff = 0; d.K = C;
@@ -820,9 +1033,10 @@ void conv1d_desc(IgemmDesc &d, const float *in, const float *w, float *out, int 
     else { d.wsk = C * 3; d.wsn = 3; }                  // k = co, j = ci
 }
 
-void wgrad1d_desc(WgradDesc &d, const float *in, const float *g, int N, int C, int H, int W, int axis, int dil)
+void wgrad1d_desc(WgradDesc &d, int dt, const void *in, const void *g, int N, int C, int H, int W, int axis, int dil)
 {
     memset(&d, 0, sizeof(d));
+    d.dt = dt;
     d.in = in; d.g = g;
     d.N = N; d.GH = H; d.GW = W;
     d.in_H = H; d.in_W = W; d.in_C = C; d.K = C;
@@ -919,9 +1133,9 @@ size_t erf_workspace_bytes(long long n_pixels, int max_c)
 }
 
 // ================================================================================ Downsampler
-int erf_downsampler_forward(const float *x, long long sn, long long sc, long long sh, long long sw,
-                            const float *w, const float *b, const erf_bn_t *bn, float *y, float *pre,
-                            int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes, void *stream)
+static int downsampler_forward_impl(int dt, const void *x, long long sn, long long sc, long long sh, long long sw,
+                                    const float *w, const float *b, const erf_bn_t *bn, void *y, void *pre,
+                                    int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
@@ -933,7 +1147,7 @@ int erf_downsampler_forward(const float *x, long long sn, long long sc, long lon
     // BatchNorm in train mode (or in eval mode when backward needs the pre-BN tensor) runs as
     // conv/pool -> pre, [statistics,] normalise + ReLU -> y; otherwise BN folds into the epilogue.
     const bool two_pass = mode == 2 || (mode == 1 && pre);
-    float *dst = two_pass ? pre : y;
+    void *dst = two_pass ? pre : y;
     if (two_pass && !pre) {
         dst = ar.floats((size_t)Mo * Cout);
         if (!dst) return fail("DownsamplerBlock: workspace too small");
@@ -945,7 +1159,7 @@ int erf_downsampler_forward(const float *x, long long sn, long long sc, long lon
     if (Cin == 3) {
         if (Cc > 16) return fail("DownsamplerBlock with 3 input channels supports at most 19 outputs");
         FirstDownDesc d = {x, sn, sc, sh, sw, w, dst, epi, N, H, W, Cc};
-        first_down_fwd_kernel<<<(unsigned)((Mo + 255) / 256), 256, 0, st>>>(d);
+        BY_DT(dt, (first_down_fwd_kernel<T><<<(unsigned)((Mo + 255) / 256), 256, 0, st>>>(d)));
         CHECK_LAUNCH("first_down_fwd_kernel");
     } else {
         if (Cin % 4 || Cout % 4) return fail("DownsamplerBlock: channel counts must be multiples of 4");
@@ -953,6 +1167,7 @@ int erf_downsampler_forward(const float *x, long long sn, long long sc, long lon
             return fail("DownsamplerBlock: input must be NHWC-contiguous");
         IgemmDesc d;
         zero_desc(d);
+        d.dt = dt;
         d.in = x; d.w = w; d.out = dst; d.epi = epi;
         d.N = N; d.GH = Ho; d.GW = Wo;
         d.in_H = H; d.in_W = W; d.in_C = Cin; d.K = Cin; d.ss = 2;
@@ -964,25 +1179,25 @@ int erf_downsampler_forward(const float *x, long long sn, long long sc, long lon
         Epilogue pe = epi;
         pe.bias = nullptr;
         PoolDesc p = {x, dst, pe, N, H, W, Cin, Cout, Cc};
-        pool_fwd_kernel<<<grid_for(Mo * (Cin / 4), 256, 1u << 30), 256, 0, st>>>(p);
+        BY_DT(dt, (pool_fwd_kernel<T><<<grid_for(Mo * (Cin / 4), 256, 1u << 30), 256, 0, st>>>(p)));
         CHECK_LAUNCH("pool_fwd_kernel");
     }
     if (two_pass) {
-        if (mode == 2) { if (bn_train_stats(bn, dst, Mo, Cout, ar, st)) return 1; }
+        if (mode == 2) { if (bn_train_stats(dt, bn, dst, Mo, Cout, ar, st)) return 1; }
         else if (bn_eval_prepare(bn, Cout, st)) return 1;
         Epilogue e = kNoEpi;
         e.bn = mode == 2 ? bn_saved_affine(bn) : bn_eval_affine(bn);
         e.relu = 1;
-        if (launch_elt(dst, y, e, Mo, Cout, Ho * Wo, st)) return 1;
+        if (launch_elt(dt, dst, y, e, Mo, Cout, Ho * Wo, st)) return 1;
     }
     return 0;
 }
 
-int erf_downsampler_backward(const float *x, long long sn, long long sc, long long sh, long long sw,
-                             const float *w, const erf_bn_t *bn, const float *y, const float *pre,
-                             const float *gy, float *dx, float *dw, float *db, float *dgamma,
-                             float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
-                             void *ws, size_t ws_bytes, void *stream)
+static int downsampler_backward_impl(int dt, const void *x, long long sn, long long sc, long long sh, long long sw,
+                                     const float *w, const erf_bn_t *bn, const void *y, const void *pre,
+                                     const void *gy, void *dx, float *dw, float *db, float *dgamma,
+                                     float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
+                                     void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
@@ -990,15 +1205,15 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
     const long long Mo = (long long)N * Ho * Wo;
     const int mode = bn_mode(bn);
     const bool premasked = (flags & ERF_BWD_GY_PREMASKED) != 0;
-    const float *g = gy;
+    const void *g = gy;
     if (mode || !premasked) {
         float *gbuf = ar.floats((size_t)Mo * Cout);
         if (!gbuf) return fail("DownsamplerBlock backward: workspace too small");
         if (mode) {
-            if (bn_backward(bn, pre, gy, premasked ? nullptr : y, nullptr, gbuf, dgamma, dbeta, Mo, Cout,
+            if (bn_backward(dt, bn, pre, gy, premasked ? nullptr : y, nullptr, gbuf, dgamma, dbeta, Mo, Cout,
                             Ho * Wo, ar, st)) return 1;
         } else {
-            if (launch_mask(gy, y, gbuf, Mo, Cout, st)) return 1;
+            if (launch_mask(dt, gy, y, gbuf, Mo, Cout, st)) return 1;
         }
         g = gbuf;
     }
@@ -1014,14 +1229,15 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         const long long x_elems = (long long)(N - 1) * sn + 2 * sc + (long long)(H - 1) * sh + (long long)(W - 1) * sw + 1;
         if (x_elems >= (1LL << 29) || Mo * Cout >= (1LL << 29) || sn < 0 || sc < 0 || sh < 0 || sw < 0)
             return fail("DownsamplerBlock backward: input too large or negatively strided");
-        FirstDownWgradDesc d = {x, sn, sc, sh, sw, g, partial, N, H, W, Cc, Cout, (int)sp, (unsigned)(x_elems * 4)};
-        first_down_wgrad_kernel<<<(unsigned)nsplit, 256, 0, st>>>(d);
+        FirstDownWgradDesc d = {x, sn, sc, sh, sw, g, partial, N, H, W, Cc, Cout, (int)sp, (unsigned)x_elems};
+        BY_DT(dt, (first_down_wgrad_kernel<T><<<(unsigned)nsplit, 256, 0, st>>>(d)));
         CHECK_LAUNCH("first_down_wgrad_kernel");
         reduce_flat_kernel<<<(nw + Cc + 31) / 32, 256, 0, st>>>(partial, dw, db, (int)nsplit, nw, Cc);
         CHECK_LAUNCH("reduce_flat_kernel");
     } else {
         WgradDesc d;
         memset(&d, 0, sizeof(d));
+        d.dt = dt;
         d.in = x; d.g = g;
         d.N = N; d.GH = Ho; d.GW = Wo;
         d.in_H = H; d.in_W = W; d.in_C = Cin; d.K = Cin; d.ss = 2; d.os = 1; d.ntaps = 9;
@@ -1033,6 +1249,7 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
             // coarse side = the gradient of the convolution output, fine side = the block input
             WgradDesc e;
             memset(&e, 0, sizeof(e));
+            e.dt = dt;
             e.in = g; e.in_C = Cout; e.K = Cc;
             e.g = x; e.g_C = Cin;
             e.N = N; e.GH = Ho; e.GW = Wo;
@@ -1045,11 +1262,12 @@ int erf_downsampler_backward(const float *x, long long sn, long long sc, long lo
         p.in = x; p.g = g; p.dx = dx; p.N = N; p.H = H; p.W = W; p.C = Cin; p.g_C = Cout; p.g_coff = Cc;
         if (Cin == 3 && (sc != 1 || sw != Cin || sh != (long long)W * Cin || sn != (long long)H * W * Cin))
             return fail("DownsamplerBlock backward: dx for a 3-channel input needs an NHWC input");
-        pool_bwd_kernel<<<grid_for(Mo * Cin, 256, 1u << 30), 256, 0, st>>>(p);
+        BY_DT(dt, (pool_bwd_kernel<T><<<grid_for(Mo * Cin, 256, 1u << 30), 256, 0, st>>>(p)));
         CHECK_LAUNCH("pool_bwd_kernel");
         const ParityTaps pt = parity_taps();
         IgemmDesc d;
         zero_desc(d);
+        d.dt = dt;
         d.in = g; d.w = w; d.out = dx;
         d.epi.res = dx; d.epi.res_C = Cin; d.epi.res_coff = 0;
         if (flags & ERF_BWD_MASK_DX) { d.epi.mask = x; d.epi.mask_C = Cin; }
@@ -1079,13 +1297,13 @@ struct Nb1dPlan {
     IgemmDesc d[4];
     int m1, m2;
     bool tp1, tp2;
-    float *p2, *t2, *p4;
+    void *p2, *t2, *p4;
     int pair12, pair_next;      // tile variants, 0 = separate launches
-    PairDesc pd12, pdn;
+    FusedPair pd12, pdn;
 };
 constexpr int kMaxChain = 8;
 
-int nb1d_chain_segment(const float *x, const erf_nb1d_block_t *blk, int nb, int N, int C, int H, int W,
+int nb1d_chain_segment(int dt, const void *x, const erf_nb1d_block_t *blk, int nb, int N, int C, int H, int W,
                        Arena &ar, hipStream_t st)
 {
     const long long M = (long long)N * H * W;
@@ -1097,13 +1315,13 @@ int nb1d_chain_segment(const float *x, const erf_nb1d_block_t *blk, int nb, int 
         const erf_nb1d_block_t &B = blk[i];
         Nb1dPlan &P = plan[i];
         if (B.dil < 1) return fail("non_bottleneck_1d: dilation must be >= 1");
-        const float *xin = i ? blk[i - 1].y : x;
+        const void *xin = i ? blk[i - 1].y : x;
         P.m1 = bn_mode(B.bn1); P.m2 = bn_mode(B.bn2);
         // Two-pass BatchNorm (conv -> pre, [statistics,] normalise) in train mode and whenever the
         // activations are saved for backward; eval-mode inference folds BN into the conv epilogue.
         P.tp1 = P.m1 == 2 || (P.m1 == 1 && B.save);
         P.tp2 = P.m2 == 2 || (P.m2 == 1 && B.save);
-        float *t1, *t3;
+        void *t1, *t3;
         if (B.save) {
             t1 = B.save[0]; P.p2 = B.save[1]; P.t2 = B.save[2]; t3 = B.save[3]; P.p4 = B.save[4];
             if ((P.m1 && !P.p2) || (P.m2 && !P.p4)) return fail("non_bottleneck_1d: BatchNorm needs the pre2/pre4 buffers");
@@ -1114,20 +1332,20 @@ int nb1d_chain_segment(const float *x, const erf_nb1d_block_t *blk, int nb, int 
         }
         IgemmDesc *d = P.d;
         // conv3x1_1 + ReLU
-        conv1d_desc(d[0], xin, B.w[0], t1, N, C, H, W, 0, 1, false);
+        conv1d_desc(d[0], dt, xin, B.w[0], t1, N, C, H, W, 0, 1, false);
         d[0].epi.bias = B.b[0]; d[0].epi.relu = 1;
         // conv1x3_1 [+ BN1] + ReLU
-        conv1d_desc(d[1], t1, B.w[1], P.tp1 ? P.p2 : P.t2, N, C, H, W, 1, 1, false);
+        conv1d_desc(d[1], dt, t1, B.w[1], P.tp1 ? P.p2 : P.t2, N, C, H, W, 1, 1, false);
         d[1].epi.bias = B.b[1];
         if (!P.tp1) {
             if (P.m1 == 1) d[1].epi.bn = bn_eval_affine(B.bn1);
             d[1].epi.relu = 1;
         }
         // conv3x1_2 (dilated) + ReLU
-        conv1d_desc(d[2], P.t2, B.w[2], t3, N, C, H, W, 0, B.dil, false);
+        conv1d_desc(d[2], dt, P.t2, B.w[2], t3, N, C, H, W, 0, B.dil, false);
         d[2].epi.bias = B.b[2]; d[2].epi.relu = 1;
         // conv1x3_2 (dilated) [+ BN2] [+ dropout] + residual + ReLU
-        conv1d_desc(d[3], t3, B.w[3], P.tp2 ? P.p4 : B.y, N, C, H, W, 1, B.dil, false);
+        conv1d_desc(d[3], dt, t3, B.w[3], P.tp2 ? P.p4 : B.y, N, C, H, W, 1, B.dil, false);
         d[3].epi.bias = B.b[3];
         if (!P.tp2) {
             if (P.m2 == 1) d[3].epi.bn = bn_eval_affine(B.bn2);
@@ -1171,19 +1389,19 @@ int nb1d_chain_segment(const float *x, const erf_nb1d_block_t *blk, int nb, int 
     for (int i = 0; i < nb; ++i) {
         const erf_nb1d_block_t &B = blk[i];
         Nb1dPlan &P = plan[i];
-        const float *xin = i ? blk[i - 1].y : x;
+        const void *xin = i ? blk[i - 1].y : x;
         if (!(i > 0 && plan[i - 1].pair_next) && run_igemm(P.d[0], st)) return 1;
         if (P.pair12) {
             if (run_pair(P.pd12, C, P.pair12, st)) return 1;
         } else {
             if (run_igemm(P.d[1], st)) return 1;
             if (P.tp1) {
-                if (P.m1 == 2) { if (bn_train_stats(B.bn1, P.p2, M, C, ar, st)) return 1; }
+                if (P.m1 == 2) { if (bn_train_stats(dt, B.bn1, P.p2, M, C, ar, st)) return 1; }
                 else if (bn_eval_prepare(B.bn1, C, st)) return 1;
                 Epilogue e = kNoEpi;
                 e.bn = P.m1 == 2 ? bn_saved_affine(B.bn1) : bn_eval_affine(B.bn1);
                 e.relu = 1;
-                if (launch_elt(P.p2, P.t2, e, M, C, H * W, st)) return 1;
+                if (launch_elt(dt, P.p2, P.t2, e, M, C, H * W, st)) return 1;
             }
             if (run_igemm(P.d[2], st)) return 1;
         }
@@ -1193,22 +1411,22 @@ int nb1d_chain_segment(const float *x, const erf_nb1d_block_t *blk, int nb, int 
         }
         if (run_igemm(P.d[3], st)) return 1;
         if (P.tp2) {
-            if (P.m2 == 2) { if (bn_train_stats(B.bn2, P.p4, M, C, ar, st)) return 1; }
+            if (P.m2 == 2) { if (bn_train_stats(dt, B.bn2, P.p4, M, C, ar, st)) return 1; }
             else if (bn_eval_prepare(B.bn2, C, st)) return 1;
             Epilogue e = kNoEpi;
             e.bn = P.m2 == 2 ? bn_saved_affine(B.bn2) : bn_eval_affine(B.bn2);
             e.nscale = B.drop_scale;
             e.res = xin; e.res_C = C; e.res_coff = 0;
             e.relu = 1;
-            if (launch_elt(P.p4, B.y, e, M, C, H * W, st)) return 1;
+            if (launch_elt(dt, P.p4, B.y, e, M, C, H * W, st)) return 1;
         }
     }
     return 0;
 }
 }  // namespace
 
-int erf_nb1d_chain_forward(const float *x, const erf_nb1d_block_t *blocks, int nblocks, int N, int C,
-                           int H, int W, void *ws, size_t ws_bytes, void *stream)
+static int nb1d_chain_forward_impl(int dt, const void *x, const erf_nb1d_block_t *blocks, int nblocks, int N, int C,
+                                   int H, int W, void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (C % 4) return fail("non_bottleneck_1d: chann must be a multiple of 4 (got %d)", C);
@@ -1220,20 +1438,20 @@ int erf_nb1d_chain_forward(const float *x, const erf_nb1d_block_t *blocks, int n
     for (int i = 0; i < nblocks; i += kMaxChain) {
         Arena ar(ws, ws_bytes);
         const int nb = nblocks - i < kMaxChain ? nblocks - i : kMaxChain;
-        if (nb1d_chain_segment(i ? blocks[i - 1].y : x, blocks + i, nb, N, C, H, W, ar, st)) return 1;
+        if (nb1d_chain_segment(dt, i ? blocks[i - 1].y : x, blocks + i, nb, N, C, H, W, ar, st)) return 1;
     }
     return 0;
 }
 
-int erf_nb1d_forward(const float *x, const float *const w[4], const float *const b[4],
-                     const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil, float *y,
-                     float *const save[5], int N, int C, int H, int W, void *ws, size_t ws_bytes,
-                     void *stream)
+static int nb1d_forward_impl(int dt, const void *x, const float *const w[4], const float *const b[4],
+                             const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil, void *y,
+                             void *const save[5], int N, int C, int H, int W, void *ws, size_t ws_bytes,
+                             void *stream)
 {
     erf_nb1d_block_t blk;
     for (int i = 0; i < 4; ++i) { blk.w[i] = w[i]; blk.b[i] = b[i]; }
     blk.bn1 = bn1; blk.bn2 = bn2; blk.drop_scale = drop_scale; blk.dil = dil; blk.y = y; blk.save = save;
-    return erf_nb1d_chain_forward(x, &blk, 1, N, C, H, W, ws, ws_bytes, stream);
+    return nb1d_chain_forward_impl(dt, x, &blk, 1, N, C, H, W, ws, ws_bytes, stream);
 }
 
 // ================================================================================ convolution pair
@@ -1265,8 +1483,8 @@ int erf_conv_pair_forward(const float *x, const float *packed, const float *b_fi
     // descriptors only for the geometry checks of pair_variant; an unstored intermediate is
     // given the input's (aligned) address there
     float *link = mid ? mid : const_cast<float *>(x);
-    conv1d_desc(a, x, nullptr, link, N, C, H, W, first_axis, dil_first, false);
-    conv1d_desc(b, link, nullptr, y, N, C, H, W, 1 - first_axis, dil_second, false);
+    conv1d_desc(a, 0, x, nullptr, link, N, C, H, W, first_axis, dil_first, false);
+    conv1d_desc(b, 0, link, nullptr, y, N, C, H, W, 1 - first_axis, dil_second, false);
     a.epi.bias = b_first; a.epi.relu = relu_first ? 1 : 0;
     b.epi.bias = b_second; b.epi.relu = relu_second ? 1 : 0;
     if (residual) { b.epi.res = residual; b.epi.res_C = C; }
@@ -1286,14 +1504,60 @@ int erf_conv_pair_forward(const float *x, const float *packed, const float *b_fi
         for (int t = 0; t < 3; ++t) { pd.s1[t] = a.tdh[t]; pd.s2[t] = b.tdw[t]; }
     }
     pd.nlines = N * pd.lines_per_img;
-    return run_pair(pd, C, tile, (hipStream_t)stream);
+    return run_pair_f32(pd, C, tile, (hipStream_t)stream);
 }
 
-int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
-                      const float *drop_scale, int dil, const float *y, const float *const save[5],
-                      const float *gy, float *dx, float *const dw[4], float *const db[4],
-                      float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, int flags,
-                      void *ws, size_t ws_bytes, void *stream)
+int erf_conv_pair_pack_bf16(const float *w_first, const float *w_second, int C, void *packed, void *stream)
+{
+    if (C != 64 && C != 128) return fail("conv pair (bf16): 64 or 128 channels (got %d)", C);
+    if (!w_first || !packed) return fail("conv pair (bf16): null weight pointer");
+    LinePackDesc pk[2];
+    const int woff[3] = {0, 1, 2};
+    line_pack_desc(pk[0], w_first, (bf16_t *)packed, C, 3, C * 3, woff);
+    if (w_second) line_pack_desc(pk[1], w_second, (bf16_t *)packed + line_packed_elems(C), C, 3, C * 3, woff);
+    return launch_line_pack(pk, w_second ? 2 : 1, (hipStream_t)stream);
+}
+
+int erf_conv_pair_forward_bf16(const void *x, const void *packed, const float *b_first, const float *b_second,
+                               int first_axis, int dil_first, int dil_second, int relu_first, int relu_second,
+                               const void *residual, void *mid, void *y, int N, int C, int H, int W,
+                               void *stream)
+{
+    if (first_axis != 0 && first_axis != 1) return fail("conv pair (bf16): first_axis is 0 (H) or 1 (W)");
+    if (dil_first < 1 || dil_second < 0) return fail("conv pair (bf16): bad dilation");
+    if (!x || !packed || !y) return fail("conv pair (bf16): null tensor pointer");
+    if (y == x || mid == x) return fail("conv pair (bf16): the outputs must not alias the input");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(mid) || !aligned16(residual) || !aligned16(packed))
+        return fail("conv pair (bf16): tensors must be 16-byte aligned");
+    if ((long long)N * H * W * C >= (1LL << 31)) return fail("conv pair (bf16): tensor too large");
+    const bool pair = dil_second > 0;
+    // the first convolution runs across the lines: along W -> lines are image columns
+    const int L = first_axis == 1 ? H : W;
+    const int BM = line_tile_bf16(C, L, pair);
+    if (!BM) return fail("conv pair (bf16): %d channels with lines of %d pixels have no kernel", C, L);
+    LineDesc ld;
+    memset(&ld, 0, sizeof(ld));
+    ld.in = (const bf16_t *)x; ld.wp1 = (const bf16_t *)packed; ld.wp2 = (const bf16_t *)packed + line_packed_elems(C);
+    ld.mid = (bf16_t *)mid; ld.out = (bf16_t *)y;
+    ld.epi1 = kNoEpi; ld.epi2 = kNoEpi;
+    ld.epi1.bias = b_first; ld.epi1.relu = relu_first ? 1 : 0;
+    ld.epi2.bias = b_second; ld.epi2.relu = relu_second ? 1 : 0;
+    Epilogue &last = pair ? ld.epi2 : ld.epi1;
+    if (residual) { last.res = residual; last.res_C = C; }
+    ld.N = N; ld.img_pixels = H * W; ld.L = L;
+    ld.segs = (L + BM - 1) / BM;
+    if (first_axis == 1) { ld.lines_per_img = W; ld.pstride = W; ld.qstride = 1; }
+    else { ld.lines_per_img = H; ld.pstride = 1; ld.qstride = W; }
+    for (int t = 0; t < 3; ++t) { ld.s1[t] = (t - 1) * dil_first; ld.s2[t] = (t - 1) * dil_second; }
+    ld.nlines = N * ld.lines_per_img;
+    return run_line(ld, C, BM, pair, (hipStream_t)stream);
+}
+
+static int nb1d_backward_impl(int dt, const void *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
+                              const float *drop_scale, int dil, const void *y, const void *const save[5],
+                              const void *gy, void *dx, float *const dw[4], float *const db[4],
+                              float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, int flags,
+                              void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
@@ -1302,36 +1566,36 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     const long long M = (long long)N * H * W;
     const size_t nel = (size_t)M * C;
     const int m1 = bn_mode(bn1), m2 = bn_mode(bn2);
-    const float *t1 = save[0], *p2 = save[1], *t2 = save[2], *t3 = save[3], *p4 = save[4];
+    const void *t1 = save[0], *p2 = save[1], *t2 = save[2], *t3 = save[3], *p4 = save[4];
     // Every tensor of the gradient chain gets a buffer of its own, so the weight gradients (helper
     // stream) can read them while the chain moves on:
     //   g4 = gy*(y>0) -> [gs = bn2'/dropout'(g4)] -> gb -> ga -> [gn = bn1'(ga)] -> g1 -> dx
     const bool premasked = (flags & ERF_BWD_GY_PREMASKED) != 0;
     float *g4buf = premasked ? nullptr : ar.floats(nel);
-    const float *g4 = premasked ? gy : g4buf;
+    const void *g4 = premasked ? gy : g4buf;
     float *ga = ar.floats(nel), *gb = ar.floats(nel), *g1 = ar.floats(nel);
     float *gsbuf = (m2 || drop_scale) ? ar.floats(nel) : nullptr;
-    const float *gs = gsbuf ? gsbuf : g4;
+    const void *gs = gsbuf ? gsbuf : g4;
     float *gnbuf = m1 ? ar.floats(nel) : nullptr;
-    const float *gn = gnbuf ? gnbuf : ga;
+    const void *gn = gnbuf ? gnbuf : ga;
     if ((!premasked && !g4buf) || !ga || !gb || !g1 || ((m2 || drop_scale) && !gsbuf) || (m1 && !gnbuf))
         return fail("non_bottleneck_1d backward: workspace too small");
     const int woff[3] = {0, 1, 2};
 
     IgemmDesc d[4];
     PackDesc pk[4];
-    conv1d_desc(d[3], gs, w[3], gb, N, C, H, W, 1, dil, true);      // masked by t3 > 0
+    conv1d_desc(d[3], dt, gs, w[3], gb, N, C, H, W, 1, dil, true);      // masked by t3 > 0
     d[3].epi.mask = t3; d[3].epi.mask_C = C;
-    conv1d_desc(d[2], gb, w[2], ga, N, C, H, W, 0, dil, true);      // masked by t2 > 0
+    conv1d_desc(d[2], dt, gb, w[2], ga, N, C, H, W, 0, dil, true);      // masked by t2 > 0
     d[2].epi.mask = t2; d[2].epi.mask_C = C;
-    conv1d_desc(d[1], gn, w[1], g1, N, C, H, W, 1, 1, true);        // masked by t1 > 0
+    conv1d_desc(d[1], dt, gn, w[1], g1, N, C, H, W, 1, 1, true);        // masked by t1 > 0
     d[1].epi.mask = t1; d[1].epi.mask_C = C;
-    conv1d_desc(d[0], g1, w[0], dx, N, C, H, W, 0, 1, true);        // + g4 (residual path)
+    conv1d_desc(d[0], dt, g1, w[0], dx, N, C, H, W, 0, 1, true);        // + g4 (residual path)
     d[0].epi.res = g4; d[0].epi.res_C = C;
     if (flags & ERF_BWD_MASK_DX) { d[0].epi.mask = x; d[0].epi.mask_C = C; }
     // each half of the chain is "along W, then along H": one launch over image columns
     const int pair32 = pair_variant(d[3], d[2]), pair10 = pair_variant(d[1], d[0]);
-    PairDesc pd32, pd10;
+    FusedPair pd32, pd10;
     if (pair32) {
         PackDesc two[2];
         if (plan_pair(d[3], d[2], true, ar, two, pd32)) return 1;
@@ -1349,21 +1613,21 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     if (!pbn) return fail("non_bottleneck_1d backward: workspace too small");
     Arena bn_ar(pbn, bn_bytes);
     // g4 = gy * (y > 0): gradient of the residual sum (goes to x unchanged and into the conv branch)
-    if (!premasked && launch_mask(gy, y, g4buf, M, C, st)) return 1;
+    if (!premasked && launch_mask(dt, gy, y, g4buf, M, C, st)) return 1;
     if (m2) {
-        if (bn_backward(bn2, p4, g4, nullptr, drop_scale, gsbuf, dgamma ? dgamma[1] : nullptr,
+        if (bn_backward(dt, bn2, p4, g4, nullptr, drop_scale, gsbuf, dgamma ? dgamma[1] : nullptr,
                         dbeta ? dbeta[1] : nullptr, M, C, H * W, bn_ar, st)) return 1;
     } else if (drop_scale) {
         Epilogue e = kNoEpi;
         e.nscale = drop_scale;
-        if (launch_elt(g4, gsbuf, e, M, C, H * W, st)) return 1;
+        if (launch_elt(dt, g4, gsbuf, e, M, C, H * W, st)) return 1;
     }
     // data-gradient chain: gs -> gb -> ga [-> gn] -> g1 -> dx = dgrad + g4
     if (pair32) {
         if (run_pair(pd32, C, pair32, st)) return 1;
     } else if (run_igemm(d[3], st) || run_igemm(d[2], st)) return 1;
     if (m1) {
-        if (bn_backward(bn1, p2, ga, nullptr, nullptr, gnbuf, dgamma ? dgamma[0] : nullptr,
+        if (bn_backward(dt, bn1, p2, ga, nullptr, nullptr, gnbuf, dgamma ? dgamma[0] : nullptr,
                         dbeta ? dbeta[0] : nullptr, M, C, H * W, bn_ar, st)) return 1;
     }
     if (pair10) {
@@ -1371,17 +1635,17 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
     } else if (run_igemm(d[1], st) || run_igemm(d[0], st)) return 1;
     // the four weight gradients in one launch: (x, g1), (t1, gn), (t2, gb), (t3, gs)
     WgradDesc wd[4];
-    wgrad1d_desc(wd[0], x, g1, N, C, H, W, 0, 1);
-    wgrad1d_desc(wd[1], t1, gn, N, C, H, W, 1, 1);
-    wgrad1d_desc(wd[2], t2, gb, N, C, H, W, 0, dil);
-    wgrad1d_desc(wd[3], t3, gs, N, C, H, W, 1, dil);
+    wgrad1d_desc(wd[0], dt, x, g1, N, C, H, W, 0, 1);
+    wgrad1d_desc(wd[1], dt, t1, gn, N, C, H, W, 1, 1);
+    wgrad1d_desc(wd[2], dt, t2, gb, N, C, H, W, 0, dil);
+    wgrad1d_desc(wd[3], dt, t3, gs, N, C, H, W, 1, dil);
     return launch_wgrad_batch(wd, 4, dw, db, woff, 3, C * 3, 1u, ar, st);
 }
 
 // ================================================================================ Upsampler
-int erf_upsampler_forward(const float *x, const float *w, const float *b, const erf_bn_t *bn, float *y,
-                          float *pre, int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes,
-                          void *stream)
+static int upsampler_forward_impl(int dt, const void *x, const float *w, const float *b, const erf_bn_t *bn, void *y,
+                                  void *pre, int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes,
+                                  void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
@@ -1389,7 +1653,7 @@ int erf_upsampler_forward(const float *x, const float *w, const float *b, const 
     const int mode = bn_mode(bn);
     const long long Mo = (long long)N * 4 * H * W;
     const bool two_pass = mode == 2 || (mode == 1 && pre);
-    float *dst = two_pass ? pre : y;
+    void *dst = two_pass ? pre : y;
     if (two_pass && !pre) {
         dst = ar.floats((size_t)Mo * Cout);
         if (!dst) return fail("UpsamplerBlock: workspace too small");
@@ -1397,6 +1661,7 @@ int erf_upsampler_forward(const float *x, const float *w, const float *b, const 
     const ParityTaps pt = parity_taps();
     IgemmDesc d;
     zero_desc(d);
+    d.dt = dt;
     d.in = x; d.w = w; d.out = dst;
     d.epi.bias = b;
     if (mode == 1 && !two_pass) d.epi.bn = bn_eval_affine(bn);
@@ -1414,35 +1679,35 @@ int erf_upsampler_forward(const float *x, const float *w, const float *b, const 
         if (launch_up16_fwd(d, st)) return 1;
     } else if (launch_igemm(d, ar, st)) return 1;
     if (two_pass) {
-        if (mode == 2) { if (bn_train_stats(bn, dst, Mo, Cout, ar, st)) return 1; }
+        if (mode == 2) { if (bn_train_stats(dt, bn, dst, Mo, Cout, ar, st)) return 1; }
         else if (bn_eval_prepare(bn, Cout, st)) return 1;
         Epilogue e = kNoEpi;
         e.bn = mode == 2 ? bn_saved_affine(bn) : bn_eval_affine(bn);
         e.relu = 1;
-        if (launch_elt(dst, y, e, Mo, Cout, 4 * H * W, st)) return 1;
+        if (launch_elt(dt, dst, y, e, Mo, Cout, 4 * H * W, st)) return 1;
     }
     return 0;
 }
 
-int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, const float *y,
-                           const float *pre, const float *gy, float *dx, float *dw, float *db,
-                           float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
-                           void *ws, size_t ws_bytes, void *stream)
+static int upsampler_backward_impl(int dt, const void *x, const float *w, const erf_bn_t *bn, const void *y,
+                                   const void *pre, const void *gy, void *dx, float *dw, float *db,
+                                   float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
+                                   void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     const int mode = bn_mode(bn);
     const long long Mo = (long long)N * 4 * H * W;
     const bool premasked = (flags & ERF_BWD_GY_PREMASKED) != 0;
-    const float *g = gy;
+    const void *g = gy;
     if (mode || !premasked) {
         float *gbuf = ar.floats((size_t)Mo * Cout);
         if (!gbuf) return fail("UpsamplerBlock backward: workspace too small");
         if (mode) {
-            if (bn_backward(bn, pre, gy, premasked ? nullptr : y, nullptr, gbuf, dgamma, dbeta, Mo, Cout,
+            if (bn_backward(dt, bn, pre, gy, premasked ? nullptr : y, nullptr, gbuf, dgamma, dbeta, Mo, Cout,
                             4 * H * W, ar, st)) return 1;
         } else {
-            if (launch_mask(gy, y, gbuf, Mo, Cout, st)) return 1;
+            if (launch_mask(dt, gy, y, gbuf, Mo, Cout, st)) return 1;
         }
         g = gbuf;
     }
@@ -1450,6 +1715,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
     {   // weight gradient over the parity classes
         WgradDesc d;
         memset(&d, 0, sizeof(d));
+        d.dt = dt;
         d.in = x; d.g = g;
         d.N = N; d.GH = H; d.GW = W;
         d.in_H = H; d.in_W = W; d.in_C = Cin; d.K = Cin; d.ss = 1; d.os = 2; d.ntaps = 9;
@@ -1466,6 +1732,7 @@ int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, c
     if (dx) {   // data gradient = ordinary 3x3 stride-2 convolution of g
         IgemmDesc d;
         zero_desc(d);
+        d.dt = dt;
         d.in = g; d.w = w; d.out = dx;
         if (flags & ERF_BWD_MASK_DX) { d.epi.mask = x; d.epi.mask_C = Cin; }
         d.N = N; d.GH = H; d.GW = W;
@@ -1488,23 +1755,30 @@ static unsigned outconv_grid(long long M)
     return (unsigned)(b < 1024 ? (b < 1 ? 1 : b) : 1024);
 }
 
-int erf_outconv_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin, int H,
-                        int W, int ncls, int softmax, void *stream)
+// dt = storage of x; out_dt = storage of the logits / probabilities
+static int outconv_forward_impl(int dt, int out_dt, const void *x, const float *w, const float *b, void *y, int N,
+                                int Cin, int H, int W, int ncls, int softmax, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (Cin != OC_CIN) return fail("output ConvTranspose2d: Cin must be %d (got %d)", OC_CIN, Cin);
     if (ncls < 1 || ncls > OC_MAX_NCLS) return fail("output ConvTranspose2d: 1 <= classes <= %d", OC_MAX_NCLS);
-    if (!aligned16(x) || ((uintptr_t)y & 7)) return fail("output ConvTranspose2d: misaligned tensors");
+    if (!aligned16(x) || ((uintptr_t)y & (out_dt ? 3 : 7))) return fail("output ConvTranspose2d: misaligned tensors");
     const long long M = (long long)N * H * W;
     OutConvDesc d = {x, w, b, y, N, H, W, ncls};
-    if (softmax) outconv_fwd_kernel<true><<<outconv_grid(M), 256, 0, st>>>(d);
-    else outconv_fwd_kernel<false><<<outconv_grid(M), 256, 0, st>>>(d);
+    if (!dt && out_dt) return fail("output ConvTranspose2d: bf16 logits need bf16 activations");
+    if (softmax) {
+        if (out_dt) outconv_fwd_kernel<true, bf16_t, bf16_t><<<outconv_grid(M), 256, 0, st>>>(d);
+        else BY_DT(dt, (outconv_fwd_kernel<true, T, float><<<outconv_grid(M), 256, 0, st>>>(d)));
+    } else {
+        if (out_dt) outconv_fwd_kernel<false, bf16_t, bf16_t><<<outconv_grid(M), 256, 0, st>>>(d);
+        else BY_DT(dt, (outconv_fwd_kernel<false, T, float><<<outconv_grid(M), 256, 0, st>>>(d)));
+    }
     CHECK_LAUNCH("outconv_fwd_kernel");
     return 0;
 }
 
-int erf_outconv_argmax(const float *x, const float *w, const float *b, long long *labels, int N, int Cin,
-                       int H, int W, int ncls, void *stream)
+static int outconv_argmax_impl(int dt, const void *x, const float *w, const float *b, long long *labels, int N, int Cin,
+                               int H, int W, int ncls, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     if (Cin != OC_CIN) return fail("output ConvTranspose2d: Cin must be %d (got %d)", OC_CIN, Cin);
@@ -1513,14 +1787,14 @@ int erf_outconv_argmax(const float *x, const float *w, const float *b, long long
     const long long M = (long long)N * H * W;
     if (M == 0) return 0;
     OutConvDesc d = {x, w, b, nullptr, N, H, W, ncls};
-    outconv_argmax_kernel<<<outconv_grid(M), 256, 0, st>>>(d, labels);
+    BY_DT(dt, (outconv_argmax_kernel<T><<<outconv_grid(M), 256, 0, st>>>(d, labels)));
     CHECK_LAUNCH("outconv_argmax_kernel");
     return 0;
 }
 
-int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw, float *db,
-                         int N, int Cin, int H, int W, int ncls, int flags, void *ws, size_t ws_bytes,
-                         void *stream)
+static int outconv_backward_impl(int dt, const void *x, const float *w, const float *gy, void *dx, float *dw, float *db,
+                                 int N, int Cin, int H, int W, int ncls, int flags, void *ws, size_t ws_bytes,
+                                 void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
@@ -1539,10 +1813,10 @@ int erf_outconv_backward(const float *x, const float *w, const float *gy, float 
     if (!partial) return fail("output ConvTranspose2d backward: workspace too small");
     OutConvBwdDesc d = {x, w, gy, dx, partial, N, H, W, ncls, (int)sp, (flags & ERF_BWD_MASK_DX) ? 1 : 0};
     if (dx) {
-        outconv_dgrad_kernel<<<outconv_grid(M), 256, 0, st>>>(d);
+        BY_DT(dt, (outconv_dgrad_kernel<T><<<outconv_grid(M), 256, 0, st>>>(d)));
         CHECK_LAUNCH("outconv_dgrad_kernel");
     }
-    outconv_wgrad_kernel<<<(unsigned)nsplit, 256, 0, st>>>(d);
+    BY_DT(dt, (outconv_wgrad_kernel<T><<<(unsigned)nsplit, 256, 0, st>>>(d)));
     CHECK_LAUNCH("outconv_wgrad_kernel");
     outconv_wreduce_kernel<<<(slab + 31) / 32, 256, 0, st>>>(partial, dw, db, (int)nsplit, ncls);
     CHECK_LAUNCH("outconv_wreduce_kernel");
@@ -1561,14 +1835,15 @@ static void conv2d_taps(int k, int *dh, int *dw, int *woff, bool transpose)
     }
 }
 
-int erf_conv2d_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin, int H,
-                       int W, int Cout, int k, int relu, void *ws, size_t ws_bytes, void *stream)
+static int conv2d_forward_impl(int dt, const void *x, const float *w, const float *b, void *y, int N, int Cin, int H,
+                               int W, int Cout, int k, int relu, void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     if (k != 1 && k != 3) return fail("conv2d: kernel size must be 1 or 3");
     IgemmDesc d;
     zero_desc(d);
+    d.dt = dt;
     d.in = x; d.w = w; d.out = y;
     d.epi.bias = b; d.epi.relu = relu;
     d.N = N; d.GH = H; d.GW = W;
@@ -1580,24 +1855,25 @@ int erf_conv2d_forward(const float *x, const float *w, const float *b, float *y,
     return launch_igemm(d, ar, st);
 }
 
-int erf_conv2d_backward(const float *x, const float *w, const float *y, const float *gy, float *dx,
-                        float *dw, float *db, int N, int Cin, int H, int W, int Cout, int k, int relu,
-                        void *ws, size_t ws_bytes, void *stream)
+static int conv2d_backward_impl(int dt, const void *x, const float *w, const void *y, const void *gy, void *dx,
+                                float *dw, float *db, int N, int Cin, int H, int W, int Cout, int k, int relu,
+                                void *ws, size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
     if (k != 1 && k != 3) return fail("conv2d: kernel size must be 1 or 3");
     const long long M = (long long)N * H * W;
-    const float *g = gy;
+    const void *g = gy;
     if (relu) {
         if (Cout % 4) return fail("conv2d backward with ReLU needs Cout %% 4 == 0");
         float *gm = ar.floats((size_t)M * Cout);
         if (!gm) return fail("conv2d backward: workspace too small");
-        if (launch_mask(gy, y, gm, M, Cout, st)) return 1;
+        if (launch_mask(dt, gy, y, gm, M, Cout, st)) return 1;
         g = gm;
     }
     WgradDesc wd;
     memset(&wd, 0, sizeof(wd));
+    wd.dt = dt;
     wd.in = x; wd.g = g;
     wd.N = N; wd.GH = H; wd.GW = W;
     wd.in_H = H; wd.in_W = W; wd.in_C = Cin; wd.K = Cin; wd.ss = 1; wd.os = 1; wd.ntaps = k * k;
@@ -1608,6 +1884,7 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
     if (dx) {
         IgemmDesc d;
         zero_desc(d);
+        d.dt = dt;
         d.in = g; d.w = w; d.out = dx;
         d.N = N; d.GH = H; d.GW = W;
         d.in_H = H; d.in_W = W; d.in_C = Cout; d.K = Cout;
@@ -1735,6 +2012,174 @@ int erf_accuracy_counts(const float *scores, const long long *target, int N, int
     acc_sum_kernel<<<1, 256, 0, st>>>(d);
     CHECK_LAUNCH("acc_sum_kernel");
     return 0;
+}
+
+
+// ================================================================================ public entry points
+// Each block call exists for fp32 tensors (the reference's arithmetic) and, suffixed _bf16, for bf16
+// activation tensors (fp32 parameters, fp32 accumulation); both run the same host logic above.
+#define ERF_DT_F32 0
+#define ERF_DT_BF16 1
+
+int erf_downsampler_forward(const float *x, long long sn, long long sc, long long sh, long long sw,
+                            const float *w, const float *b, const erf_bn_t *bn, float *y, float *pre,
+                            int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes, void *stream)
+{
+    return downsampler_forward_impl(ERF_DT_F32, x, sn, sc, sh, sw, w, b, bn, y, pre, N, Cin, H, W, Cout, ws, ws_bytes, stream);
+}
+int erf_downsampler_forward_bf16(const void *x, long long sn, long long sc, long long sh, long long sw,
+                                 const float *w, const float *b, const erf_bn_t *bn, void *y, void *pre,
+                                 int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes, void *stream)
+{
+    return downsampler_forward_impl(ERF_DT_BF16, x, sn, sc, sh, sw, w, b, bn, y, pre, N, Cin, H, W, Cout, ws, ws_bytes, stream);
+}
+int erf_downsampler_backward(const float *x, long long sn, long long sc, long long sh, long long sw,
+                             const float *w, const erf_bn_t *bn, const float *y, const float *pre,
+                             const float *gy, float *dx, float *dw, float *db, float *dgamma,
+                             float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
+                             void *ws, size_t ws_bytes, void *stream)
+{
+    return downsampler_backward_impl(ERF_DT_F32, x, sn, sc, sh, sw, w, bn, y, pre, gy, dx, dw, db, dgamma, dbeta, N, Cin,
+                                     H, W, Cout, flags, ws, ws_bytes, stream);
+}
+int erf_downsampler_backward_bf16(const void *x, long long sn, long long sc, long long sh, long long sw,
+                                  const float *w, const erf_bn_t *bn, const void *y, const void *pre,
+                                  const void *gy, void *dx, float *dw, float *db, float *dgamma,
+                                  float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
+                                  void *ws, size_t ws_bytes, void *stream)
+{
+    return downsampler_backward_impl(ERF_DT_BF16, x, sn, sc, sh, sw, w, bn, y, pre, gy, dx, dw, db, dgamma, dbeta, N, Cin,
+                                     H, W, Cout, flags, ws, ws_bytes, stream);
+}
+
+int erf_nb1d_forward(const float *x, const float *const w[4], const float *const b[4],
+                     const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil, float *y,
+                     float *const save[5], int N, int C, int H, int W, void *ws, size_t ws_bytes,
+                     void *stream)
+{
+    return nb1d_forward_impl(ERF_DT_F32, x, w, b, bn1, bn2, drop_scale, dil, y, (void *const *)save, N, C, H, W, ws,
+                             ws_bytes, stream);
+}
+int erf_nb1d_forward_bf16(const void *x, const float *const w[4], const float *const b[4],
+                          const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil, void *y,
+                          void *const save[5], int N, int C, int H, int W, void *ws, size_t ws_bytes,
+                          void *stream)
+{
+    return nb1d_forward_impl(ERF_DT_BF16, x, w, b, bn1, bn2, drop_scale, dil, y, save, N, C, H, W, ws, ws_bytes, stream);
+}
+int erf_nb1d_chain_forward(const float *x, const erf_nb1d_block_t *blocks, int nblocks, int N, int C,
+                           int H, int W, void *ws, size_t ws_bytes, void *stream)
+{
+    return nb1d_chain_forward_impl(ERF_DT_F32, x, blocks, nblocks, N, C, H, W, ws, ws_bytes, stream);
+}
+int erf_nb1d_chain_forward_bf16(const void *x, const erf_nb1d_block_t *blocks, int nblocks, int N, int C,
+                                int H, int W, void *ws, size_t ws_bytes, void *stream)
+{
+    return nb1d_chain_forward_impl(ERF_DT_BF16, x, blocks, nblocks, N, C, H, W, ws, ws_bytes, stream);
+}
+int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
+                      const float *drop_scale, int dil, const float *y, const float *const save[5],
+                      const float *gy, float *dx, float *const dw[4], float *const db[4],
+                      float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, int flags,
+                      void *ws, size_t ws_bytes, void *stream)
+{
+    return nb1d_backward_impl(ERF_DT_F32, x, w, bn1, bn2, drop_scale, dil, y, (const void *const *)save, gy, dx, dw, db,
+                              dgamma, dbeta, N, C, H, W, flags, ws, ws_bytes, stream);
+}
+int erf_nb1d_backward_bf16(const void *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
+                           const float *drop_scale, int dil, const void *y, const void *const save[5],
+                           const void *gy, void *dx, float *const dw[4], float *const db[4],
+                           float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, int flags,
+                           void *ws, size_t ws_bytes, void *stream)
+{
+    return nb1d_backward_impl(ERF_DT_BF16, x, w, bn1, bn2, drop_scale, dil, y, save, gy, dx, dw, db, dgamma, dbeta, N, C,
+                              H, W, flags, ws, ws_bytes, stream);
+}
+
+int erf_upsampler_forward(const float *x, const float *w, const float *b, const erf_bn_t *bn, float *y,
+                          float *pre, int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes,
+                          void *stream)
+{
+    return upsampler_forward_impl(ERF_DT_F32, x, w, b, bn, y, pre, N, Cin, H, W, Cout, ws, ws_bytes, stream);
+}
+int erf_upsampler_forward_bf16(const void *x, const float *w, const float *b, const erf_bn_t *bn, void *y,
+                               void *pre, int N, int Cin, int H, int W, int Cout, void *ws, size_t ws_bytes,
+                               void *stream)
+{
+    return upsampler_forward_impl(ERF_DT_BF16, x, w, b, bn, y, pre, N, Cin, H, W, Cout, ws, ws_bytes, stream);
+}
+int erf_upsampler_backward(const float *x, const float *w, const erf_bn_t *bn, const float *y,
+                           const float *pre, const float *gy, float *dx, float *dw, float *db,
+                           float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
+                           void *ws, size_t ws_bytes, void *stream)
+{
+    return upsampler_backward_impl(ERF_DT_F32, x, w, bn, y, pre, gy, dx, dw, db, dgamma, dbeta, N, Cin, H, W, Cout, flags,
+                                   ws, ws_bytes, stream);
+}
+int erf_upsampler_backward_bf16(const void *x, const float *w, const erf_bn_t *bn, const void *y,
+                                const void *pre, const void *gy, void *dx, float *dw, float *db,
+                                float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout, int flags,
+                                void *ws, size_t ws_bytes, void *stream)
+{
+    return upsampler_backward_impl(ERF_DT_BF16, x, w, bn, y, pre, gy, dx, dw, db, dgamma, dbeta, N, Cin, H, W, Cout, flags,
+                                   ws, ws_bytes, stream);
+}
+
+int erf_outconv_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin, int H,
+                        int W, int ncls, int softmax, void *stream)
+{
+    return outconv_forward_impl(ERF_DT_F32, ERF_DT_F32, x, w, b, y, N, Cin, H, W, ncls, softmax, stream);
+}
+int erf_outconv_forward_bf16(const void *x, const float *w, const float *b, void *y, int y_is_bf16, int N,
+                             int Cin, int H, int W, int ncls, int softmax, void *stream)
+{
+    return outconv_forward_impl(ERF_DT_BF16, y_is_bf16 ? ERF_DT_BF16 : ERF_DT_F32, x, w, b, y, N, Cin, H, W, ncls,
+                                softmax, stream);
+}
+int erf_outconv_argmax(const float *x, const float *w, const float *b, long long *labels, int N, int Cin,
+                       int H, int W, int ncls, void *stream)
+{
+    return outconv_argmax_impl(ERF_DT_F32, x, w, b, labels, N, Cin, H, W, ncls, stream);
+}
+int erf_outconv_argmax_bf16(const void *x, const float *w, const float *b, long long *labels, int N, int Cin,
+                            int H, int W, int ncls, void *stream)
+{
+    return outconv_argmax_impl(ERF_DT_BF16, x, w, b, labels, N, Cin, H, W, ncls, stream);
+}
+int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw, float *db,
+                         int N, int Cin, int H, int W, int ncls, int flags, void *ws, size_t ws_bytes,
+                         void *stream)
+{
+    return outconv_backward_impl(ERF_DT_F32, x, w, gy, dx, dw, db, N, Cin, H, W, ncls, flags, ws, ws_bytes, stream);
+}
+int erf_outconv_backward_bf16(const void *x, const float *w, const float *gy, void *dx, float *dw, float *db,
+                              int N, int Cin, int H, int W, int ncls, int flags, void *ws, size_t ws_bytes,
+                              void *stream)
+{
+    return outconv_backward_impl(ERF_DT_BF16, x, w, gy, dx, dw, db, N, Cin, H, W, ncls, flags, ws, ws_bytes, stream);
+}
+
+int erf_conv2d_forward(const float *x, const float *w, const float *b, float *y, int N, int Cin, int H,
+                       int W, int Cout, int k, int relu, void *ws, size_t ws_bytes, void *stream)
+{
+    return conv2d_forward_impl(ERF_DT_F32, x, w, b, y, N, Cin, H, W, Cout, k, relu, ws, ws_bytes, stream);
+}
+int erf_conv2d_forward_bf16(const void *x, const float *w, const float *b, void *y, int N, int Cin, int H,
+                            int W, int Cout, int k, int relu, void *ws, size_t ws_bytes, void *stream)
+{
+    return conv2d_forward_impl(ERF_DT_BF16, x, w, b, y, N, Cin, H, W, Cout, k, relu, ws, ws_bytes, stream);
+}
+int erf_conv2d_backward(const float *x, const float *w, const float *y, const float *gy, float *dx,
+                        float *dw, float *db, int N, int Cin, int H, int W, int Cout, int k, int relu,
+                        void *ws, size_t ws_bytes, void *stream)
+{
+    return conv2d_backward_impl(ERF_DT_F32, x, w, y, gy, dx, dw, db, N, Cin, H, W, Cout, k, relu, ws, ws_bytes, stream);
+}
+int erf_conv2d_backward_bf16(const void *x, const float *w, const void *y, const void *gy, void *dx,
+                             float *dw, float *db, int N, int Cin, int H, int W, int Cout, int k, int relu,
+                             void *ws, size_t ws_bytes, void *stream)
+{
+    return conv2d_backward_impl(ERF_DT_BF16, x, w, y, gy, dx, dw, db, N, Cin, H, W, Cout, k, relu, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

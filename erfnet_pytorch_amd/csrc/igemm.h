@@ -37,8 +37,10 @@ __device__ __forceinline__ int a_swz(int row, int chunk)
 struct PackDesc {
     const float *w;
     float *wp;
-    int ntaps, K, Nout, Npad, wsk, wsn, kc;    // kc = channels per K-step (16 or 32)
+    int ntaps, K, Nout, Npad, wsk, wsn, kc;    // kc = channels per K-step (16 or 32); 0 = nothing to pack here
     int woff[ERF_MAX_TAPS];
+    int line;                                  // 1 = bf16 MFMA fragments for the line kernel (K = Nout = 64 / 128) into lwp
+    bf16_t *lwp;
 };
 #define ERF_PACK_BATCH 32
 struct PackBatch {
@@ -74,7 +76,9 @@ struct RowInfo {          // per output pixel of the block tile
 // Main loop: LDS double buffering with one barrier per K-step.  In step s a wave first writes the
 // tile of step s+1 (loaded into registers during step s-1) into the buffer that was read in step
 // s-1, issues the global loads of step s+2, and then runs the MFMAs of step s from the other buffer.
-template <int WM, int WN, int GM, int GN, int KC, int MINW, bool VEC>
+// T = storage type of the activation tensors (fp32, or bf16 widened to fp32 on its way into LDS: the
+// arithmetic is the fp32 MFMA either way).
+template <int WM, int WN, int GM, int GN, int KC, int MINW, bool VEC, typename T = float>
 __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const IgemmDesc d)
 {
     constexpr int BM = GM * WM * 32, BN = GN * WN * 32, NT = GM * GN * 64;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
     // or a padded channel presents an out-of-range offset and loads zero, so every load is issued
     // unconditionally and its value is used as it is (a branch around a load, or a select behind
     // it, makes the compiler wait for each load separately and serialises their latencies).
-    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, (unsigned)d.N * d.in_H * d.in_W * d.in_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, (unsigned)d.N * d.in_H * d.in_W * d.in_C * Act<T>::B);
 
     auto load_step = [&](int s, Stage &R) {
         const int t = tap0 + s / kchunks;
@@ -166,16 +170,16 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
             const int kk = kc0 + ac * 4;
             const bool ok = slot < A_SLOTS && ri.src_base >= 0 && (unsigned)ih < (unsigned)d.in_H &&
                             (unsigned)iw < (unsigned)d.in_W && kk < d.K;
-            unsigned off = ((unsigned)(ri.src_base + ih * d.in_W + iw) * d.in_C + d.in_coff + kk) * 4u;
+            unsigned off = (unsigned)(ri.src_base + ih * d.in_W + iw) * d.in_C + d.in_coff + kk;
             off |= ok ? 0u : ERF_OOB;
             if (VEC) {
-                R.a[i] = buf_load4(r_in, off);
+                R.a[i] = Act<T>::load4(r_in, off);
             } else {        // channel counts / alignment that rule out 16-byte loads (rare)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) R.a[i][e] = buf_load1(r_in, (off + 4u * e) | (kk + e < d.K ? 0u : ERF_OOB));
+                for (int e = 0; e < 4; ++e) R.a[i][e] = Act<T>::load1(r_in, (off + e) | (kk + e < d.K ? 0u : ERF_OOB));
             }
         }
-        const float *wt = d.wp + ((long long)(t * kchunks + kc) * d.Npad + j0) * KC;
+        const float *wt = (const float *)d.wp + ((long long)(t * kchunks + kc) * d.Npad + j0) * KC;
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) {
             const int slot = tid + i * NT;
@@ -250,9 +254,9 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
     // a padded column or an absent optional tensor (zero records) is an out-of-range access, which
     // loads zero and drops the store, so the code has no per-element branch or 64-bit address.
     const unsigned Pout = (unsigned)d.N * d.out_H * d.out_W;
-    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, Pout * d.out_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, Pout * d.out_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * Act<T>::B);
     const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, (unsigned)d.N * d.Nout * 4u);
     const bool has_mask = d.epi.mask != nullptr, has_ns = d.epi.nscale != nullptr, relu = d.epi.relu != 0;
 #pragma unroll
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const unsigned bad = rbad[q] | cbad[b];
-                    rres[q] = buf_load1(r_res, ((opx[q] * d.epi.res_C + d.epi.res_coff + cc[b]) * 4u) | bad);
-                    rmask[q] = buf_load1(r_mask, ((opx[q] * d.epi.mask_C + d.epi.mask_coff + cc[b]) * 4u) | bad);
+                    rres[q] = Act<T>::load1(r_res, (opx[q] * d.epi.res_C + d.epi.res_coff + cc[b]) | bad);
+                    rmask[q] = Act<T>::load1(r_mask, (opx[q] * d.epi.mask_C + d.epi.mask_coff + cc[b]) | bad);
                     rns[q] = buf_load1(r_ns, ((onn[q] + cc[b]) * 4u) | bad);
                 }
 #pragma unroll
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
                     v = (has_ns ? v * rns[q] : v) + rres[q];
                     if (relu) v = fmaxf(v, 0.0f);
                     v = (!has_mask || rmask[q] > 0.0f) ? v : 0.0f;
-                    buf_store1(r_out, ((opx[q] * d.out_C + d.out_coff + cc[b]) * 4u) | rbad[q] | cbad[b], v);
+                    Act<T>::store1(r_out, (opx[q] * d.out_C + d.out_coff + cc[b]) | rbad[q] | cbad[b], v);
                 }
             }
         }
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_f32_kernel(const Igem
 // (lanes walk the channel, the two lane halves take pixel 2s and 2s+1).  PM = pixels per step:
 // 32 for the large tiles; the small-channel tiles take 64-128 so that a step carries enough MFMAs
 // for its two barriers.
-template <int IB, int JB, int GI, int GJ, bool VEC, int PM = 32>
+template <int IB, int JB, int GI, int GJ, bool VEC, int PM = 32, typename T = float>
 __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradBatch batch)
 {
     const WgradDesc &d = batch.d[blockIdx.z];      // up to four convolutions per launch
@@ -377,8 +381,8 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradBatch
     };
 
     // operands through buffer descriptors: masked slots load zero (see igemm_f32_kernel)
-    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, (unsigned)d.N * d.in_H * d.in_W * d.in_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, (unsigned)d.N * d.g_H * d.g_W * d.g_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, (unsigned)d.N * d.in_H * d.in_W * d.in_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, (unsigned)d.N * d.g_H * d.g_W * d.g_C * Act<T>::B);
     auto load_step = [&](int s) {
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
@@ -388,12 +392,12 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradBatch
             const int ih = e.y + dh, iw = e.z + dw;
             const bool ok = slot < XV && e.x >= 0 && i0 + c < d.K && (unsigned)ih < (unsigned)d.in_H &&
                             (unsigned)iw < (unsigned)d.in_W;
-            unsigned off = ((unsigned)(e.x + ih * d.in_W + iw) * d.in_C + d.in_coff + i0 + c) * 4u;
+            unsigned off = (unsigned)(e.x + ih * d.in_W + iw) * d.in_C + d.in_coff + i0 + c;
             off |= ok ? 0u : ERF_OOB;
-            if (VEC) xreg[i] = buf_load4(r_x, off);
+            if (VEC) xreg[i] = Act<T>::load4(r_x, off);
             else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xreg[i][q] = buf_load1(r_x, (off + 4u * q) | (i0 + c + q < d.K ? 0u : ERF_OOB));
+                for (int q = 0; q < 4; ++q) xreg[i][q] = Act<T>::load1(r_x, (off + q) | (i0 + c + q < d.K ? 0u : ERF_OOB));
             }
         }
 #pragma unroll
@@ -402,12 +406,12 @@ __global__ __launch_bounds__(GI *GJ * 64) void wgrad_f32_kernel(const WgradBatch
             const int p = slot / (JBLK / 4), c = (slot % (JBLK / 4)) * 4;
             const int4 e = ptab[s & 1][p < PM ? p : 0];
             const bool ok = slot < GV && e.x >= 0 && j0 + c < d.Nout;
-            unsigned off = ((unsigned)e.w * d.g_C + d.g_coff + j0 + c) * 4u;
+            unsigned off = (unsigned)e.w * d.g_C + d.g_coff + j0 + c;
             off |= ok ? 0u : ERF_OOB;
-            if (VEC) greg[i] = buf_load4(r_g, off);
+            if (VEC) greg[i] = Act<T>::load4(r_g, off);
             else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) greg[i][q] = buf_load1(r_g, (off + 4u * q) | (j0 + c + q < d.Nout ? 0u : ERF_OOB));
+                for (int q = 0; q < 4; ++q) greg[i][q] = Act<T>::load1(r_g, (off + q) | (j0 + c + q < d.Nout ? 0u : ERF_OOB));
             }
         }
     };

@@ -26,7 +26,7 @@
 // sit in LDS as [tap][k/16][c][16 k]: a wave's ds_read_b128 covers 1 KiB contiguous (no conflicts).
 // A lane loads channels 16q+4g..+3 of its coarse source pixels; MFMA number m takes element m, so
 // the instruction's k index g stands for channel 16q + 4g + m on both operands.
-template <int KQ>
+template <typename T, int KQ>
 __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
 {
     __shared__ __attribute__((aligned(16))) float Wl[9 * KQ * 256];
@@ -40,10 +40,10 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
 
     const unsigned H = (unsigned)d.GH, W = (unsigned)d.GW, M = (unsigned)d.N * H * W, HW = H * W;
     const unsigned Pout = M * 4u;
-    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, M * d.in_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, Pout * d.out_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, M * d.in_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, Pout * d.out_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * Act<T>::B);
     const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
     const bool has_mask = d.epi.mask != nullptr, relu = d.epi.relu != 0;
 
@@ -75,9 +75,9 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
         for (int s = 0; s < 4; ++s) {
             const unsigned ys = y + (s >> 1), xx = x + (s & 1);
             const bool ok = valid && ys < H && xx < W;
-            const unsigned off = (((n * H + ys) * W + xx) * d.in_C + d.in_coff + 4 * g) * 4u;
+            const unsigned off = ((n * H + ys) * W + xx) * d.in_C + d.in_coff + 4 * g;
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) xs[s][q] = buf_load4(r_in, ok ? off + q * 64u : ERF_OOB);
+            for (int q = 0; q < KQ; ++q) xs[s][q] = Act<T>::load4(r_in, ok ? off + q * 16u : ERF_OOB);
         }
         // epilogue operands of the four fine pixels
         unsigned ooff[4];
@@ -85,9 +85,9 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
-            ooff[c] = valid ? (px * d.out_C + d.out_coff + 4 * g) * 4u : ERF_OOB;
-            rres[c] = buf_load4(r_res, valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) * 4u : ERF_OOB);
-            rmask[c] = buf_load4(r_mask, valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) * 4u : ERF_OOB);
+            ooff[c] = valid ? (px * d.out_C + d.out_coff + 4 * g) : ERF_OOB;
+            rres[c] = Act<T>::load4(r_res, valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) : ERF_OOB);
+            rmask[c] = Act<T>::load4(r_mask, valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) : ERF_OOB);
         }
         f32x4 acc[4];
 #pragma unroll
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
                 if (relu) e = fmaxf(e, 0.0f);
                 v[r] = (!has_mask || rmask[c][r] > 0.0f) ? e : 0.0f;
             }
-            buf_store4(r_out, ooff[c], v);
+            Act<T>::store4(r_out, ooff[c], v);
         }
     }
 }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
 // a fixed order and the block writes one slab:
 //   [9][K][16] weight partials, [9][16] bias rows (row 0 = sum of the fine tensor, rest zero),
 //   [K] sums of the coarse tensor (the bias gradient when the coarse side is the convolution output).
-template <int KQ>
+template <typename T, int KQ>
 __global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
 {
     constexpr int NACC = 9 * KQ, NW_ = NACC * 256, SLOTS = NW_ + 16 + 16 * KQ;
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
     const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
     unsigned wend = wbeg + wsp;
     if (wend > M) wend = M;
-    const __amdgpu_buffer_rsrc_t r_c = make_rsrc(d.in, M * d.in_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_f = make_rsrc(d.g, M * 4u * d.g_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_c = make_rsrc(d.in, M * d.in_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_f = make_rsrc(d.g, M * 4u * d.g_C * Act<T>::B);
 
     f32x4 acc[NACC];
 #pragma unroll
@@ -178,14 +178,14 @@ __global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
         for (int s = 0; s < 4; ++s) {
             const unsigned ys = y + (s >> 1), xx = x + (s & 1);
             const bool ok = valid && ys < H && xx < W;
-            const unsigned off = (((n * H + ys) * W + xx) * d.in_C + d.in_coff + i) * 4u;
+            const unsigned off = ((n * H + ys) * W + xx) * d.in_C + d.in_coff + i;
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) f.cs[s][q] = buf_load1(r_c, ok ? off + (q0 + q) * 64u : ERF_OOB);
+            for (int q = 0; q < KQ; ++q) f.cs[s][q] = Act<T>::load1(r_c, ok ? off + (q0 + q) * 16u : ERF_OOB);
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
-            f.fc[c] = buf_load1(r_f, valid ? (px * d.g_C + d.g_coff + i) * 4u : ERF_OOB);
+            f.fc[c] = Act<T>::load1(r_f, valid ? (px * d.g_C + d.g_coff + i) : ERF_OOB);
         }
     };
     auto mfma_group = [&](const Frag &f) {

@@ -18,7 +18,7 @@
 // A lane loads channels 4g..4g+3 of pixel i; MFMA number m of a tap takes element m, i.e. the
 // instruction's k index g stands for channel 4g + m, and the weight operand uses the same map.
 // One wave = U tiles of 16 consecutive pixels (independent accumulators hide the MFMA latency).
-template <int NTAPS, int U, int G = 1>
+template <typename T, int NTAPS, int U, int G = 1>
 __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
 {
     const int lane = threadIdx.x & 63;
@@ -28,9 +28,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
     const unsigned base0 = ((unsigned)blockIdx.x * 4 + wave) * (16 * U * G);
     if (base0 >= M) return;
     const unsigned Pin = (unsigned)d.N * d.in_H * d.in_W, Pout = (unsigned)d.N * d.out_H * d.out_W;
-    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, Pin * d.in_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, Pin * d.in_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * Act<T>::B);
     const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, (unsigned)d.N * 64u);
     const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
     const bool has_ns = d.epi.nscale != nullptr, has_mask = d.epi.mask != nullptr, has_res = d.epi.res != nullptr;
@@ -84,15 +84,15 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
         for (int t = 0; t < NTAPS; ++t) {
             const int ih = (int)gi + d.tdh[t], iw = (int)gj + d.tdw[t];
             const unsigned bad = (unsigned)((ih | iw | (d.in_H - 1 - ih) | (d.in_W - 1 - iw)) >> 31) & ERF_OOB;
-            const unsigned off = (((n * d.in_H + ih) * d.in_W + iw) * d.in_C + d.in_coff + 4 * g) * 4u;
-            xv[u][t] = buf_load4(r_in, off | bad | vbad);
+            const unsigned off = ((n * d.in_H + ih) * d.in_W + iw) * d.in_C + d.in_coff + 4 * g;
+            xv[u][t] = Act<T>::load4(r_in, off | bad | vbad);
         }
         rres[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         rmask[u] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
         rns[u] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
         // absent tensors are skipped with wave-uniform branches (no registers held for them)
-        if (has_res) rres[u] = buf_load4(r_res, ((px * d.epi.res_C + d.epi.res_coff + 4 * g) * 4u) | vbad);
-        if (has_mask) rmask[u] = buf_load4(r_mask, ((px * d.epi.mask_C + d.epi.mask_coff + 4 * g) * 4u) | vbad);
+        if (has_res) rres[u] = Act<T>::load4(r_res, (px * d.epi.res_C + d.epi.res_coff + 4 * g) | vbad);
+        if (has_mask) rmask[u] = Act<T>::load4(r_mask, (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) | vbad);
         if (has_ns) rns[u] = buf_load4(r_ns, (n * 16 + 4 * g) * 4u);
         tgj += 16;                                   // uniform advance to the next tile
         while (tgj >= (unsigned)d.GW) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
             v[r] = rmask[u][r] > 0.0f ? e : 0.0f;
         }
         if (opix[u] >= 0)
-            *reinterpret_cast<f32x4 *>(d.out + (unsigned)opix[u] * d.out_C + d.out_coff + 4 * g) = v;
+            Act<T>::st4(d.out, (long long)((unsigned)opix[u] * d.out_C + d.out_coff + 4 * g), v);
     }
     }
 }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
 // access covers 4 pixels x 64 B.  Every wave keeps one accumulator per tap over its pixel range;
 // the waves of a block are summed through LDS in a fixed order and written as one slab in the
 // layout reduce_partials_kernel expects ([tap][k][j], then one bias row per tap).
-template <int NTAPS, int NW>
+template <typename T, int NTAPS, int NW>
 __global__ __launch_bounds__(NW * 64) void wgrad16_kernel(const WgradDesc d)
 {
     constexpr int SLOTS = NTAPS * 256 + 16;
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad16_kernel(const WgradDesc d)
     const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
     unsigned wend = wbeg + wsp;
     if (wend > M) wend = M;
-    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, M * d.in_C * 4u);
-    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, M * d.g_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, M * d.in_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, M * d.g_C * Act<T>::B);
 
     f32x4 acc[NTAPS];
 #pragma unroll
@@ -170,10 +170,10 @@ __global__ __launch_bounds__(NW * 64) void wgrad16_kernel(const WgradDesc d)
             for (int t = 0; t < NTAPS; ++t) {
                 const int ih = (int)oh + d.tdh[t], iw = (int)ow + d.tdw[t];
                 const bool ok = valid && (unsigned)ih < H && (unsigned)iw < W;
-                const unsigned off = ((unsigned)((int)m + d.tdh[t] * (int)W + d.tdw[t]) * d.in_C + d.in_coff + i) * 4u;
-                xa[u][t] = buf_load1(r_x, ok ? off : ERF_OOB);
+                const unsigned off = (unsigned)((int)m + d.tdh[t] * (int)W + d.tdw[t]) * d.in_C + d.in_coff + i;
+                xa[u][t] = Act<T>::load1(r_x, ok ? off : ERF_OOB);
             }
-            gv[u] = buf_load1(r_g, valid ? (m * d.g_C + d.g_coff + i) * 4u : ERF_OOB);
+            gv[u] = Act<T>::load1(r_g, valid ? (m * d.g_C + d.g_coff + i) : ERF_OOB);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -14,7 +14,7 @@
 #include "common.h"
 
 struct WgradLineDesc {
-    const float *in, *g;
+    const void *in, *g;     // storage type T
     float *partial;
     int N, img_pixels, Len, lines_per_img;
     int pstride;            // pixel-index distance between neighbours on a line
@@ -28,7 +28,7 @@ struct WgradLineBatch {
 
 // NC channels on both sides; block tile = all NC input channels x JBLK = GJ*JB*32 output channels,
 // GI*IB*32 = NC, 4 or 8 waves.  grid = (slabs, NC / JBLK, convolutions).
-template <int NC, int IB, int JB, int GI, int GJ, int MINB>
+template <int NC, int IB, int JB, int GI, int GJ, int MINB, typename T = float>
 __global__ __launch_bounds__(GI *GJ * 64, MINB) void wgrad_line_kernel(const WgradLineBatch batch)
 {
     const WgradLineDesc &d = batch.d[blockIdx.z];
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(GI *GJ * 64, MINB) void wgrad_line_kernel(const Wgr
     for (int b = 0; b < JB; ++b) bsum[b] = 0.0f;
 
     const unsigned P = (unsigned)d.N * d.img_pixels;
-    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, P * NC * 4u);
-    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, P * NC * 4u);
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, P * NC * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, P * NC * Act<T>::B);
     f32x4 xreg[XP], greg[GP];
 
     auto load_seg = [&](int s) {
@@ -79,18 +79,18 @@ __global__ __launch_bounds__(GI *GJ * 64, MINB) void wgrad_line_kernel(const Wgr
             const int slot = tid + i * NT;
             const int r = slot / XQ, c = (slot % XQ) * 4;
             const int q = q0 - dil + r;
-            unsigned off = ((base + (unsigned)(q * d.pstride)) * NC + c) * 4u;
+            unsigned off = (base + (unsigned)(q * d.pstride)) * NC + c;
             off |= (unsigned)(((xrows - 1 - r) | q | (d.Len - 1 - q)) >> 31) & ERF_OOB;
-            xreg[i] = buf_load4(r_x, off);
+            xreg[i] = Act<T>::load4(r_x, off);
         }
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
             const int slot = tid + i * NT;
             const int r = slot / GQ, c = (slot % GQ) * 4;
             const int q = q0 + r;
-            unsigned off = ((base + (unsigned)(q * d.pstride)) * NC + j0 + c) * 4u;
+            unsigned off = (base + (unsigned)(q * d.pstride)) * NC + j0 + c;
             off |= (unsigned)((d.Len - 1 - q) >> 31) & ERF_OOB;
-            greg[i] = buf_load4(r_g, off);
+            greg[i] = Act<T>::load4(r_g, off);
         }
     };
     auto store_seg = [&]() {

@@ -120,8 +120,8 @@ typedef struct {
     const erf_bn_t *bn1, *bn2;
     const float *drop_scale;
     int dil;
-    float *y;
-    float *const *save;
+    void *y;                /* fp32 tensors for erf_nb1d_chain_forward, bf16 for the _bf16 variant */
+    void *const *save;
 } erf_nb1d_block_t;
 int erf_nb1d_chain_forward(const float *x, const erf_nb1d_block_t *blocks, int nblocks, int N, int C,
                            int H, int W, void *ws, size_t ws_bytes, void *stream);
