@@ -190,7 +190,7 @@ int run_line(const LineDesc &ld, int NC, int BM, bool pair, hipStream_t st)
 // A 3-tap 1-D convolution described as an implicit GEMM -> geometry of the line kernel.  The taps
 // run across the lines: a convolution along W takes image columns as lines, one along H image rows.
 // Returns false when the convolution does not fit the kernel.
-bool line_geometry(const IgemmDesc &d, LineDesc &ld)
+bool line_geometry(const IgemmDesc &d, LineDesc &ld, bool reads_memory = true)
 {
     const int NC = d.K;
     if (NC != 64 && NC != 128) return false;
@@ -198,7 +198,8 @@ bool line_geometry(const IgemmDesc &d, LineDesc &ld)
     if (d.ss != 1 || d.os != 1 || d.ngroups != 1 || d.gtap0[0] != 0 || d.gntaps[0] != 3) return false;
     if (d.goa[0] || d.gob[0] || d.epi.nscale) return false;
     if (d.in_H != d.GH || d.in_W != d.GW || d.out_H != d.GH || d.out_W != d.GW) return false;
-    if (!aligned16(d.in) || !aligned16(d.out) || d.in == d.out) return false;
+    // (the second convolution of a pair takes its input from LDS: its `in` may alias anything)
+    if (!aligned16(d.in) || !aligned16(d.out) || (reads_memory && d.in == d.out)) return false;
     const long long P = (long long)d.N * d.GH * d.GW;
     if (P * NC >= (1LL << 31)) return false;
     if (d.epi.res && (d.epi.res_C != NC || d.epi.res_coff || !aligned16(d.epi.res))) return false;
@@ -458,7 +459,7 @@ int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = fa
     if (a.dt != b.dt) return 0;
     if (a.dt) {          // bf16: both halves must fit the line kernel, the second running along the first's lines
         LineDesc la, lb;
-        if (!line_geometry(a, la) || !line_geometry(b, lb) || b.in != a.out || b.K != NC) return 0;
+        if (!line_geometry(a, la) || !line_geometry(b, lb, false) || b.in != a.out || b.K != NC) return 0;
         if (a.N != b.N || a.GH != b.GH || a.GW != b.GW) return 0;
         if (a.epi.res) return 0;                            // the residual tile belongs to the second epilogue
         if (la.pstride == lb.pstride) return 0;             // same axis: not a pair
@@ -506,7 +507,7 @@ int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, 
         return fail("conv pair: the output must not alias the input (other blocks still read it)");
     if (a.dt) {
         LineDesc &ld = fp.ld, lb;
-        if (!line_geometry(a, ld) || !line_geometry(b, lb)) return fail("conv pair (bf16): geometry");
+        if (!line_geometry(a, ld) || !line_geometry(b, lb, false)) return fail("conv pair (bf16): geometry");
         bf16_t *wp = (bf16_t *)ar.take(2 * line_packed_elems(NC) * sizeof(bf16_t));
         if (!wp) return fail("conv pair: workspace too small for the weight fragments");
         for (int i = 0; i < 2; ++i) {

@@ -44,10 +44,22 @@ def _is_nhwc_dense(x):
     return x.permute(0, 2, 3, 1).is_contiguous()
 
 
-def _nhwc(x):
-    """Dense NHWC fp32 view/copy of a logical-NCHW tensor."""
-    if x.dtype != torch.float32:
-        raise TypeError(f"erfnet_hip kernels compute in fp32, got {x.dtype}")
+_ACT_DTYPES = (torch.float32, torch.bfloat16)
+
+
+def _check_act(x):
+    if x.dtype not in _ACT_DTYPES:
+        raise TypeError(f"erfnet_hip kernels store activations as fp32 or bf16, got {x.dtype}")
+
+
+def _nhwc(x, dtype=None):
+    """Dense NHWC view/copy of a logical-NCHW tensor (fp32 or bf16; ``dtype`` forces the storage
+    type, e.g. a gradient arriving in fp32 for bf16 activations)."""
+    _check_act(x)
+    if dtype is not None and x.dtype != dtype:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device, memory_format=torch.channels_last)
+        out.copy_(x)
+        return out
     if _is_nhwc_dense(x):
         return x
     out = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
@@ -56,22 +68,44 @@ def _nhwc(x):
 
 
 def _empty_nhwc(n, c, h, w, like):
-    return torch.empty((n, c, h, w), dtype=torch.float32, device=like.device,
+    return torch.empty((n, c, h, w), dtype=like.dtype, device=like.device,
                        memory_format=torch.channels_last)
+
+
+def _fn(name, x):
+    """Entry point for the storage type of ``x``: ``name`` for fp32, ``name_bf16`` for bf16."""
+    return getattr(_lib.lib(), name + "_bf16" if x.dtype == torch.bfloat16 else name)
+
+
+# Parameters are handed to the library in fp32 (the kernels repack / round them per call).  A model
+# converted with .bfloat16() is served through fp32 copies, refreshed when a parameter changes.
+_fp32_copies = {}
+
+
+def _as_fp32(t):
+    key = (t.device, t.data_ptr(), tuple(t.shape))
+    hit = _fp32_copies.get(key)
+    if hit is not None and hit[0] == t._version and hit[1].dtype == t.dtype:
+        return hit[2]
+    if len(_fp32_copies) > 4096:
+        _fp32_copies.clear()
+    c = t.detach().to(torch.float32).contiguous()
+    _fp32_copies[key] = (t._version, t, c)
+    return c
 
 
 def _param(t):
     if t is None:
         return None
     if t.dtype != torch.float32:
-        raise TypeError("parameters must be fp32")
+        return _as_fp32(t)
     return t.detach().contiguous()
 
 
 def _plain(t):
     """A parameter whose memory is handed to the library as it is (fp32, dense)."""
     if t.dtype != torch.float32:
-        raise TypeError("parameters must be fp32")
+        return _as_fp32(t)
     return t if t.is_contiguous() else t.detach().contiguous()
 
 
@@ -82,6 +116,11 @@ class _Bn:
                  saved=None):
         self.mode = int(mode)
         self.gamma, self.beta = _param(gamma), _param(beta)
+        if running_mean is not None and running_mean.dtype != torch.float32:
+            if self.mode == 2:
+                raise TypeError("BatchNorm in train mode needs fp32 running statistics (keep the module in fp32 "
+                                "and feed bf16 activations)")
+            running_mean, running_var = _as_fp32(running_mean), _as_fp32(running_var)
         self.rm, self.rv = running_mean, running_var
         self.momentum, self.eps = float(momentum), float(eps)
         self.save_mean = self.save_invstd = None
@@ -214,6 +253,12 @@ def _deliver(targets):
     return res
 
 
+def _match_params(grads, params):
+    """Gradients come out of the kernels in fp32; a parameter kept in another dtype gets a cast."""
+    return tuple(g if (g is None or p is None or g.dtype == p.dtype) else g.to(p.dtype)
+                 for g, p in zip(grads, params))
+
+
 # ------------------------------------------------------------------------------ DownsamplerBlock
 class _Downsampler(torch.autograd.Function):
     @staticmethod
@@ -225,8 +270,8 @@ class _Downsampler(torch.autograd.Function):
         ctx.out_token = out_token
         if cin != 3 or ctx.needs_input_grad[0]:
             x = _nhwc(x)     # a 3-channel image is read through its strides unless dx is wanted
-        elif x.dtype != torch.float32:
-            raise TypeError("erfnet_hip kernels compute in fp32")
+        else:
+            _check_act(x)
         need = out_token.grad_on and any(ctx.needs_input_grad)
         bn = _Bn(mode, gamma, beta, rm, rv, momentum, eps, need)
         wq, bq = _param(w), _param(b)
@@ -238,7 +283,7 @@ class _Downsampler(torch.autograd.Function):
         ws = _workspace(x, n * (h // 2) * (wd // 2), cout)
         sn, sc, sh, sw = x.stride()
         with _dev_ctx(x):
-            _lib.check(lib.erf_downsampler_forward(_p(x), sn, sc, sh, sw, _p(wq), _p(bq), bn.ref(),
+            _lib.check(_fn("erf_downsampler_forward", x)(_p(x), sn, sc, sh, sw, _p(wq), _p(bq), bn.ref(),
                                                    _p(y), _p(pre), n, cin, h, wd, cout, _p(ws),
                                                    ws.numel(), _stream(x)))
         if need:
@@ -254,7 +299,7 @@ class _Downsampler(torch.autograd.Function):
         mode, momentum, eps = ctx.cfg
         n, cin, h, wd = x.shape
         cout = y.shape[1]
-        gy = _nhwc(gy)
+        gy = _nhwc(gy, y.dtype)
         bn = _Bn(mode, gamma, None, None, None, momentum, eps, False, saved=(smean, sinv))
         need_dx = ctx.needs_input_grad[0]
         dx = _empty_nhwc(n, cin, h, wd, x) if need_dx else None
@@ -265,11 +310,11 @@ class _Downsampler(torch.autograd.Function):
         sn, sc, sh, sw = x.stride()
         flags = _bwd_flags(ctx, gy) if need_dx else (_bwd_flags(ctx, gy) & _lib.BWD_GY_PREMASKED)
         with _dev_ctx(x):
-            _lib.check(lib.erf_downsampler_backward(_p(x), sn, sc, sh, sw, _p(wq), bn.ref(), _p(y),
+            _lib.check(_fn("erf_downsampler_backward", x)(_p(x), sn, sc, sh, sw, _p(wq), bn.ref(), _p(y),
                                                     _p(pre), _p(gy), _p(dx), _p(dw), _p(db), _p(dg),
                                                     _p(dbt), n, cin, h, wd, cout, flags, _p(ws),
                                                     ws.numel(), _stream(x)))
-        dw, db, dg, dbt = _deliver(tg)
+        dw, db, dg, dbt = _match_params(_deliver(tg), ctx.params)
         return _hand_over(ctx, dx), dw, db, dg, dbt, None, None, None, None, None, None
 
 
@@ -307,7 +352,7 @@ class _Nb1d(torch.autograd.Function):
             save = [t1, p2, t2, t3, p4]
         ws = _workspace(x, n * h * wd, c)
         with _dev_ctx(x):
-            _lib.check(lib.erf_nb1d_forward(_p(x), _arr(ws_), _arr(bs_), bn1.ref(), bn2.ref(), _p(ds),
+            _lib.check(_fn("erf_nb1d_forward", x)(_p(x), _arr(ws_), _arr(bs_), bn1.ref(), bn2.ref(), _p(ds),
                                             int(dil), _p(y), None if save is None else _arr(save),
                                             n, c, h, wd, _p(ws), ws.numel(), _stream(x)))
         if need:
@@ -323,7 +368,7 @@ class _Nb1d(torch.autograd.Function):
         (x, y, t1, p2, t2, t3, p4, w0, w1, w2, w3, g1, g2, sm1, si1, sm2, si2, ds) = ctx.saved_tensors
         dil, mode, momentum, eps = ctx.cfg
         n, c, h, wd = x.shape
-        gy = _nhwc(gy)
+        gy = _nhwc(gy, x.dtype)
         bn1 = _Bn(mode, g1, None, None, None, momentum, eps, False, saved=(sm1, si1))
         bn2 = _Bn(mode, g2, None, None, None, momentum, eps, False, saved=(sm2, si2))
         dx = torch.empty_like(x)
@@ -336,11 +381,11 @@ class _Nb1d(torch.autograd.Function):
         ws = _workspace(x, n * h * wd, c)
         flags = _bwd_flags(ctx, gy)
         with _dev_ctx(x):
-            _lib.check(lib.erf_nb1d_backward(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
+            _lib.check(_fn("erf_nb1d_backward", x)(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
                                              dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
                                              _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
                                              flags, _p(ws), ws.numel(), _stream(x)))
-        return (_hand_over(ctx, dx), *_deliver(tg), None, None, None, None, None, None, None, None, None,
+        return (_hand_over(ctx, dx), *_match_params(_deliver(tg), ctx.params), None, None, None, None, None, None, None, None, None,
                 None)
 
 
@@ -419,8 +464,8 @@ class _Nb1dChain(torch.autograd.Function):
             per_block.append((y, save, ws_, bn1, bn2, ds))
         ws = _workspace(x, n * h * wd, c)
         with _dev_ctx(x):
-            _lib.check(lib.erf_nb1d_chain_forward(_p(x), blocks, nb, n, c, h, wd, _p(ws), ws.numel(),
-                                                  _stream(x)))
+            _lib.check(_fn("erf_nb1d_chain_forward", x)(_p(x), blocks, nb, n, c, h, wd, _p(ws), ws.numel(),
+                                                        _stream(x)))
         if need:
             tensors = [x]
             for y, save, ws_, bn1, bn2, ds in per_block:
@@ -439,7 +484,7 @@ class _Nb1dChain(torch.autograd.Function):
         n, c, h, wd = x0.shape
         nb = len(ctx.cfg)
         per = 17            # tensors saved per block
-        gy = _nhwc(gy)
+        gy = _nhwc(gy, x0.dtype)
         last_flags = _bwd_flags(ctx, gy)
         grads = [None] * (nb * 12)
         ws = _workspace(x0, n * h * wd, c)
@@ -466,11 +511,11 @@ class _Nb1dChain(torch.autograd.Function):
             if i > 0 or ctx.in_token is not None:
                 flags |= _lib.BWD_MASK_DX
             with _dev_ctx(x):
-                _lib.check(lib.erf_nb1d_backward(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
+                _lib.check(_fn("erf_nb1d_backward", x)(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
                                                  dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
                                                  _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
                                                  flags, _p(ws), ws.numel(), _stream(x)))
-            grads[i * 12:(i + 1) * 12] = _deliver(tg)
+            grads[i * 12:(i + 1) * 12] = _match_params(_deliver(tg), params)
             gy = dx
         return (_hand_over(ctx, gy), None, None, *grads)
 
@@ -515,6 +560,8 @@ def conv_pair(x, packed, b_first, b_second, first_axis, dil_first=1, dil_second=
     (3,1) kernels; 0: (3,1) then (1,3).  Returns y, or (y, mid) with keep_mid.  Raises when the
     image geometry has no fused kernel."""
     x = _nhwc(x.detach())
+    if x.dtype != torch.float32:
+        raise TypeError("conv_pair takes fp32 tensors (bf16: conv_pair_bf16)")
     n, c, h, wd = x.shape
     y = torch.empty_like(x)
     mid = torch.empty_like(x) if keep_mid else None
@@ -544,7 +591,7 @@ class _Upsampler(torch.autograd.Function):
         pre = torch.empty_like(y) if (mode and need) else None
         ws = _workspace(x, n * 4 * h * wd, max(cin, cout))
         with _dev_ctx(x):
-            _lib.check(lib.erf_upsampler_forward(_p(x), _p(wq), _p(bq), bn.ref(), _p(y), _p(pre), n, cin,
+            _lib.check(_fn("erf_upsampler_forward", x)(_p(x), _p(wq), _p(bq), bn.ref(), _p(y), _p(pre), n, cin,
                                                  h, wd, cout, _p(ws), ws.numel(), _stream(x)))
         if need:
             ctx.save_for_backward(x, wq, y, pre, bn.gamma, bn.save_mean, bn.save_invstd)
@@ -559,7 +606,7 @@ class _Upsampler(torch.autograd.Function):
         mode, momentum, eps = ctx.cfg
         n, cin, h, wd = x.shape
         cout = y.shape[1]
-        gy = _nhwc(gy)
+        gy = _nhwc(gy, y.dtype)
         bn = _Bn(mode, gamma, None, None, None, momentum, eps, False, saved=(smean, sinv))
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         cvec = (cout,) if mode else None
@@ -570,10 +617,10 @@ class _Upsampler(torch.autograd.Function):
         if dx is None:
             flags &= _lib.BWD_GY_PREMASKED
         with _dev_ctx(x):
-            _lib.check(lib.erf_upsampler_backward(_p(x), _p(wq), bn.ref(), _p(y), _p(pre), _p(gy), _p(dx),
+            _lib.check(_fn("erf_upsampler_backward", x)(_p(x), _p(wq), bn.ref(), _p(y), _p(pre), _p(gy), _p(dx),
                                                   _p(dw), _p(db), _p(dg), _p(dbt), n, cin, h, wd, cout,
                                                   flags, _p(ws), ws.numel(), _stream(x)))
-        dw, db, dg, dbt = _deliver(tg)
+        dw, db, dg, dbt = _match_params(_deliver(tg), ctx.params)
         return _hand_over(ctx, dx), dw, db, dg, dbt, None, None, None, None, None, None
 
 
@@ -596,10 +643,7 @@ class _OutConv(torch.autograd.Function):
         n, cin, h, wd = x.shape
         ncls = w.shape[1]
         wq, bq = _param(w), _param(b)
-        y = torch.empty((n, ncls, 2 * h, 2 * wd), dtype=torch.float32, device=x.device)
-        with _dev_ctx(x):
-            _lib.check(lib.erf_outconv_forward(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, ncls, 0,
-                                               _stream(x)))
+        y = _outconv_call(x, wq, bq, n, cin, h, wd, ncls, 0, False)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, wq)
             ctx.has_bias = b is not None
@@ -614,23 +658,46 @@ class _OutConv(torch.autograd.Function):
         ncls = wq.shape[1]
         gy = gy.contiguous()
         if gy.dtype != torch.float32:
-            raise TypeError("erfnet_hip kernels compute in fp32")
+            gy = gy.float()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         tg = _grad_targets(ctx.params, (wq.shape, (ncls,)), x.device)
         dw, db = tg[0][0], tg[1][0]
         ws = _workspace(x, n * h * wd, 16)
         flags = _lib.BWD_MASK_DX if (ctx.in_token is not None and dx is not None) else 0
         with _dev_ctx(x):
-            _lib.check(lib.erf_outconv_backward(_p(x), _p(wq), _p(gy), _p(dx), _p(dw), _p(db), n, cin, h,
-                                                wd, ncls, flags, _p(ws), ws.numel(), _stream(x)))
-        dw, db = _deliver(tg)
+            _lib.check(_fn("erf_outconv_backward", x)(_p(x), _p(wq), _p(gy), _p(dx), _p(dw), _p(db), n, cin, h,
+                                                      wd, ncls, flags, _p(ws), ws.numel(), _stream(x)))
+        dw, db = _match_params(_deliver(tg), ctx.params)
         return _hand_over(ctx, dx), dw, (db if ctx.has_bias else None)
+
+
+def _outconv_call(x, wq, bq, n, cin, h, wd, ncls, softmax, bf16_out):
+    """Launch the output transposed convolution; bf16 activations give bf16 or fp32 logits."""
+    lib = _lib.lib()
+    if x.dtype == torch.bfloat16:
+        y = torch.empty((n, ncls, 2 * h, 2 * wd), dtype=torch.bfloat16 if bf16_out else torch.float32,
+                        device=x.device)
+        with _dev_ctx(x):
+            _lib.check(lib.erf_outconv_forward_bf16(_p(x), _p(wq), _p(bq), _p(y), int(bool(bf16_out)), n, cin, h,
+                                                    wd, ncls, int(softmax), _stream(x)))
+        return y
+    y = torch.empty((n, ncls, 2 * h, 2 * wd), dtype=torch.float32, device=x.device)
+    with _dev_ctx(x):
+        _lib.check(lib.erf_outconv_forward(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, ncls, int(softmax),
+                                           _stream(x)))
+    return y
 
 
 def outconv(x, w, b):
     """nn.ConvTranspose2d(Cin, ncls, 2, stride=2) (train/net_classification.py:56,64) on the GPU.
-    Returns NCHW-contiguous logits."""
-    return _apply(_OutConv, x, w, b)
+    Returns NCHW-contiguous logits.  bf16 activations: the logits are fp32 while an autograd graph is
+    being built (they feed the loss), bf16 under torch.no_grad() (half the bytes of the largest
+    tensor of the network)."""
+    if torch.is_grad_enabled():
+        return _OutConv.apply(x, w, b)
+    x = _nhwc(x)
+    n, cin, h, wd = x.shape
+    return _outconv_call(x, _param(w), _param(b), n, cin, h, wd, w.shape[1], 0, x.dtype == torch.bfloat16)
 
 
 def outconv_softmax(x, w, b):
@@ -640,12 +707,7 @@ def outconv_softmax(x, w, b):
     x = _nhwc(x)
     n, cin, h, wd = x.shape
     ncls = w.shape[1]
-    wq, bq = _param(w), _param(b)
-    y = torch.empty((n, ncls, 2 * h, 2 * wd), dtype=torch.float32, device=x.device)
-    with _dev_ctx(x):
-        _lib.check(lib.erf_outconv_forward(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, ncls, 1,
-                                           _stream(x)))
-    return y
+    return _outconv_call(x, _param(w), _param(b), n, cin, h, wd, ncls, 1, x.dtype == torch.bfloat16)
 
 
 def outconv_argmax(x, w, b):
@@ -658,7 +720,7 @@ def outconv_argmax(x, w, b):
     wq, bq = _param(w), _param(b)
     labels = torch.empty((n, 1, 2 * h, 2 * wd), dtype=torch.int64, device=x.device)
     with _dev_ctx(x):
-        _lib.check(lib.erf_outconv_argmax(_p(x), _p(wq), _p(bq), _p(labels), n, cin, h, wd, ncls, _stream(x)))
+        _lib.check(_fn("erf_outconv_argmax", x)(_p(x), _p(wq), _p(bq), _p(labels), n, cin, h, wd, ncls, _stream(x)))
     return labels
 
 
@@ -674,8 +736,8 @@ class _Conv2d(torch.autograd.Function):
         y = _empty_nhwc(n, cout, h, wd, x)
         ws = _workspace(x, n * h * wd, max(cin, cout))
         with _dev_ctx(x):
-            _lib.check(lib.erf_conv2d_forward(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, cout, k,
-                                              int(relu), _p(ws), ws.numel(), _stream(x)))
+            _lib.check(_fn("erf_conv2d_forward", x)(_p(x), _p(wq), _p(bq), _p(y), n, cin, h, wd, cout, k,
+                                                    int(relu), _p(ws), ws.numel(), _stream(x)))
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, wq, y if relu else None)
             ctx.cfg = (k, int(relu), b is not None)
@@ -689,15 +751,15 @@ class _Conv2d(torch.autograd.Function):
         k, relu, has_bias = ctx.cfg
         n, cin, h, wd = x.shape
         cout = wq.shape[0]
-        gy = _nhwc(gy)
+        gy = _nhwc(gy, x.dtype)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         tg = _grad_targets(ctx.params, (wq.shape, (cout,)), x.device)
         dw, db = tg[0][0], tg[1][0]
         ws = _workspace(x, n * h * wd, max(cin, cout))
         with _dev_ctx(x):
-            _lib.check(lib.erf_conv2d_backward(_p(x), _p(wq), _p(y), _p(gy), _p(dx), _p(dw), _p(db), n, cin,
-                                               h, wd, cout, k, relu, _p(ws), ws.numel(), _stream(x)))
-        dw, db = _deliver(tg)
+            _lib.check(_fn("erf_conv2d_backward", x)(_p(x), _p(wq), _p(y), _p(gy), _p(dx), _p(dw), _p(db), n, cin,
+                                                     h, wd, cout, k, relu, _p(ws), ws.numel(), _stream(x)))
+        dw, db = _match_params(_deliver(tg), ctx.params)
         return dx, dw, (db if has_bias else None), None
 
 
@@ -713,7 +775,7 @@ class _CrossEntropy(torch.autograd.Function):
     def forward(ctx, logits, target, ignore_index):
         lib = _lib.lib()
         if logits.dtype != torch.float32:
-            raise TypeError(f"erfnet_hip kernels compute in fp32, got {logits.dtype}")
+            raise TypeError(f"cross_entropy: the loss reads fp32 logits, got {logits.dtype}")
         if target.dtype != torch.int64:
             raise TypeError(f"cross_entropy: target must be int64 class indices, got {target.dtype}")
         n, k, h, wd = logits.shape

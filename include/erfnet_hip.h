@@ -234,6 +234,71 @@ int erf_iou_add_batch(const long long *pred, const long long *target, long long 
 int erf_accuracy_counts(const float *scores, const long long *target, int N, int K, int H, int W,
                         long long *counts, void *ws, size_t ws_bytes, void *stream);
 
+/* ================================================================================================
+ * bf16 storage.  Every block call above exists a second time, suffixed _bf16, for activation tensors
+ * stored as bf16 (the reference's half-precision attempt is eval/eval_forwardTime.py:25,
+ * `model.half()`; bf16 is the 16-bit type gfx950's matrix cores take).  Same arguments and meaning:
+ *   - activation / gradient tensors (x, y, pre, save[], gy, dx, residual, mid, the block structs' y
+ *     and save) are bf16, NHWC, 16-byte aligned;
+ *   - parameters, biases, BatchNorm vectors, dropout factors and every parameter gradient stay fp32
+ *     (the kernels round the weights to bf16 when they repack them; products are accumulated in
+ *     fp32; bias, BatchNorm, residual and ReLU are applied in fp32 before the one rounding of the
+ *     stored result);
+ *   - the 64 / 128-channel 1-D convolutions run on v_mfma_f32_32x32x16_bf16 with the weights held
+ *     in registers (csrc/line_bf16.h); other layers widen bf16 to fp32 on their way into the fp32
+ *     kernels.
+ * Expected agreement with the fp32 entry points: 1e-2 of the output's scale. */
+int erf_downsampler_forward_bf16(const void *x, long long sn, long long sc, long long sh, long long sw,
+                                 const float *w, const float *b, const erf_bn_t *bn, void *y,
+                                 void *pre, int N, int Cin, int H, int W, int Cout, void *ws,
+                                 size_t ws_bytes, void *stream);
+int erf_downsampler_backward_bf16(const void *x, long long sn, long long sc, long long sh,
+                                  long long sw, const float *w, const erf_bn_t *bn, const void *y,
+                                  const void *pre, const void *gy, void *dx, float *dw, float *db,
+                                  float *dgamma, float *dbeta, int N, int Cin, int H, int W,
+                                  int Cout, int flags, void *ws, size_t ws_bytes, void *stream);
+int erf_nb1d_forward_bf16(const void *x, const float *const w[4], const float *const b[4],
+                          const erf_bn_t *bn1, const erf_bn_t *bn2, const float *drop_scale, int dil,
+                          void *y, void *const save[5], int N, int C, int H, int W, void *ws,
+                          size_t ws_bytes, void *stream);
+int erf_nb1d_chain_forward_bf16(const void *x, const erf_nb1d_block_t *blocks, int nblocks, int N,
+                                int C, int H, int W, void *ws, size_t ws_bytes, void *stream);
+int erf_nb1d_backward_bf16(const void *x, const float *const w[4], const erf_bn_t *bn1,
+                           const erf_bn_t *bn2, const float *drop_scale, int dil, const void *y,
+                           const void *const save[5], const void *gy, void *dx, float *const dw[4],
+                           float *const db[4], float *const dgamma[2], float *const dbeta[2], int N,
+                           int C, int H, int W, int flags, void *ws, size_t ws_bytes, void *stream);
+/* packed: 2*3*C*C bf16 (MFMA weight fragments).  w_second may be NULL and dil_second 0: a single
+ * convolution, y = act(conv_first(x) + b_first [+ residual]).  Lines longer than a tile (C = 128: 128
+ * pixels, C = 64: 256) are accepted for a single convolution only. */
+int erf_conv_pair_pack_bf16(const float *w_first, const float *w_second, int C, void *packed, void *stream);
+int erf_conv_pair_forward_bf16(const void *x, const void *packed, const float *b_first,
+                               const float *b_second, int first_axis, int dil_first, int dil_second,
+                               int relu_first, int relu_second, const void *residual, void *mid,
+                               void *y, int N, int C, int H, int W, void *stream);
+int erf_upsampler_forward_bf16(const void *x, const float *w, const float *b, const erf_bn_t *bn,
+                               void *y, void *pre, int N, int Cin, int H, int W, int Cout, void *ws,
+                               size_t ws_bytes, void *stream);
+int erf_upsampler_backward_bf16(const void *x, const float *w, const erf_bn_t *bn, const void *y,
+                                const void *pre, const void *gy, void *dx, float *dw, float *db,
+                                float *dgamma, float *dbeta, int N, int Cin, int H, int W, int Cout,
+                                int flags, void *ws, size_t ws_bytes, void *stream);
+/* y_is_bf16 = 0: fp32 logits (they feed the loss in training); 1: bf16 logits (inference). */
+int erf_outconv_forward_bf16(const void *x, const float *w, const float *b, void *y, int y_is_bf16,
+                             int N, int Cin, int H, int W, int ncls, int softmax, void *stream);
+int erf_outconv_argmax_bf16(const void *x, const float *w, const float *b, long long *labels, int N,
+                            int Cin, int H, int W, int ncls, void *stream);
+/* gy: fp32 gradient of the fp32 logits; dx bf16. */
+int erf_outconv_backward_bf16(const void *x, const float *w, const float *gy, void *dx, float *dw,
+                              float *db, int N, int Cin, int H, int W, int ncls, int flags, void *ws,
+                              size_t ws_bytes, void *stream);
+int erf_conv2d_forward_bf16(const void *x, const float *w, const float *b, void *y, int N, int Cin,
+                            int H, int W, int Cout, int k, int relu, void *ws, size_t ws_bytes,
+                            void *stream);
+int erf_conv2d_backward_bf16(const void *x, const float *w, const void *y, const void *gy, void *dx,
+                             float *dw, float *db, int N, int Cin, int H, int W, int Cout, int k,
+                             int relu, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

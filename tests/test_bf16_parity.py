@@ -98,3 +98,145 @@ def test_line_kernel_against_fp64(c, h, w, first_axis, d1, d2, pair, res):
     if pair:
         _check(m, mid, "mid", tol=2.0 ** -7)
     _check(y, out, "out", tol=2.0 ** -7)
+
+
+# ------------------------------------------------------------------------------------------------
+# The module API on bf16 activations against the goldens generated from the reference (fp32).
+# Forward bound: 1e-2 of the tensor's scale (north star: 1e-2 for bf16).  Gradients of a block go
+# through three more roundings and ReLU masks that may flip: 3e-2 of scale, 2 % outliers.
+from test_boundary_cpu import MODELS, first, make_model  # noqa: E402
+
+MAN = gu.load_json("manifest.json")
+BLK = gu.load_npz("blocks.npz")
+NETS = gu.load_npz("nets.npz")
+CASES = {c["name"]: c for c in MAN["block_cases"]}
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _check_grad_l2(name, arr, tol=0.2):
+    """Gradients against the fp32 golden in relative L2.  A bf16 forward moves every pre-activation
+    by up to ~1e-2 of its scale, so on Gaussian test data about one ReLU mask in a hundred differs
+    from the fp32 run; each flip is a full-size change of one gradient term, which bounds what an
+    elementwise comparison can show (a wrong kernel gives a relative L2 error of order 1).  The strict
+    comparison, with the masks pinned by shared saved activations, is
+    test_nb1d_backward_bf16_strict below."""
+    if name in BLK:
+        g = BLK[name].astype(np.float64)
+        a = arr.astype(np.float64)
+    else:
+        idx = gu.sample_index(name, arr.size)
+        g = BLK[name + "#samp"].astype(np.float64)
+        a = arr.reshape(-1)[idx].astype(np.float64)
+    assert g.shape == a.shape, name
+    den = np.sqrt((g * g).sum())
+    err = np.sqrt(((a - g) ** 2).sum())
+    if den < 1e-3 * np.sqrt(g.size):
+        # mathematically zero (the bias in front of a train-mode BatchNorm): what is left is the
+        # cancellation error of a sum over thousands of pixels of bf16-rounded terms of order one
+        # (2^-9 * sqrt(pixels) per channel)
+        assert err <= 0.3 * np.sqrt(g.size), f"{name} bf16: {err:.3g} against a zero gradient"
+        return
+    assert err <= tol * den + 1e-6, f"{name} bf16: relative L2 error {err / max(den, 1e-30):.3g}"
+
+
+def _build_block(c):
+    from test_hip_parity import build_block
+    return build_block(c)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("name", [n for n, c in CASES.items() if c["kind"] not in ("conv1x1", "softmaxconv")])
+def test_block_bf16_against_golden(name, monkeypatch):
+    from erfnet_pytorch_amd import _lib
+    c = CASES[name]
+    mod = gu.fill_state_dict(_build_block(c), tag=name).to(DEV)
+    mod.train(c["bn_mode"] == 2)
+    if c.get("drop_scale_key"):
+        from erfnet_pytorch_amd import erfnet_blocks as eb
+        n, ch = c["inputs"][0][0], c["inputs"][0][1]
+        keep = (gu.det_uniform(c["drop_scale_key"], (n, ch, 1, 1), 0, 1) >= c["p"]).astype(np.float32)
+        scale = _t(keep.reshape(n, ch) / (1.0 - c["p"]))
+        monkeypatch.setattr(eb, "_dropout2d_scale", lambda x, p, active: scale)
+        mod.train(True)
+    xs = []
+    for i, s in enumerate(c["inputs"]):
+        x = gu.det_normal(f"{name}.x{i}", tuple(s))
+        if name.endswith("relu_in"):
+            x = np.maximum(x, 0)
+        xs.append(_t(x).to(BF).requires_grad_(True))
+    before = _lib.launch_count()
+    y = mod(*xs)
+    assert _lib.launch_count() > before
+    if c["kind"] != "outconv":
+        assert y.dtype == BF
+    gu.check(BLK, f"{name}/y", y.detach().float().cpu().numpy(), 1e-5, 0.0, what=f"{name}/y bf16", scale_rtol=1e-2)
+    gy = _t(gu.det_normal(f"{name}.gy", tuple(y.shape))).to(y.dtype)
+    y.backward(gy)
+    for i, x in enumerate(xs):
+        _check_grad_l2(f"{name}/dx{i}", x.grad.float().cpu().numpy())
+    for k, p in mod.named_parameters():
+        if f"{name}/d:{k}" in BLK or f"{name}/d:{k}#samp" in BLK:
+            assert p.grad is not None and p.grad.dtype == torch.float32, k
+            _check_grad_l2(f"{name}/d:{k}", p.grad.cpu().numpy())
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("key", ["eval_erfnet_nobn_19", "net_classification_20", "eval_erfnet_20", "net_regression_0"])
+def test_whole_net_small_bf16(key):
+    if key not in MODELS:
+        pytest.skip(f"no model {key}")
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    x = _t(gu.det_uniform("net.x_small", (1, 3, 64, 128), 0.0, 1.0)).to(BF)
+    with torch.no_grad():
+        y = first(net(x))
+    assert y.dtype == BF
+    y = y.float().cpu().numpy()
+    gu.check(NETS, f"{key}/small/y", y, 1e-5, 0.0, what=f"{key} bf16 logits", scale_rtol=1e-2)
+    if y.shape[1] > 1:
+        g = NETS[f"{key}/small/y"] if f"{key}/small/y" in NETS else None
+        if g is not None:
+            srt = np.sort(g, axis=1)
+            scale = np.abs(g).max()
+            ok = (srt[:, -1] - srt[:, -2]) > 2e-2 * scale       # non-tie pixels at the bf16 bound
+            assert ok.mean() > 0.5
+            assert np.array_equal(y.argmax(1).astype(np.uint8)[ok], NETS[f"{key}/small/argmax"][ok])
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("key", ["eval_erfnet_20", "net_classification_20"])
+def test_whole_net_512x1024_bf16(key):
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    x = _t(gu.det_uniform("net.x_big", (1, 3, 512, 1024), 0.0, 1.0)).to(BF)
+    with torch.no_grad():
+        y = first(net(x)).float().cpu().numpy()
+    # 72 stacked convolutions in bf16: 1e-2 of the logits' scale holds for all but a tail of the ten
+    # million logits; the tail (at most one in a thousand) stays within 3e-2
+    gu.check(NETS, f"{key}/big/y", y, 1e-5, 0.0, what=f"{key} bf16 logits", scale_rtol=1e-2, outlier_frac=1e-3,
+             outlier_rtol=3e-2)
+    crop = NETS[f"{key}/big/crop"]
+    scale = float(NETS[f"{key}/big/y#stat"][2])
+    cerr = np.abs(y[:, :, 224:288, 480:544] - crop)
+    assert (cerr > 1e-2 * scale).mean() <= 1e-3 and cerr.max() <= 3e-2 * scale
+    ok = NETS[f"{key}/big/margin"].astype(np.float32) > 2e-2 * scale
+    assert ok.mean() > 0.5
+    assert np.array_equal(y.argmax(1).astype(np.uint8)[ok], NETS[f"{key}/big/argmax"][ok])
+
+
+@pytest.mark.timeout(300)
+def test_bf16_module_matches_bf16_activations_with_fp32_module():
+    """model.bfloat16() (bf16 parameters) gives the same numbers as fp32 parameters fed bf16 images
+    whenever the parameters are representable: the kernels round the weights to bf16 either way."""
+    key = "net_classification_20"
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    x = _t(gu.det_uniform("net.x_small", (1, 3, 64, 128), 0.0, 1.0)).to(BF)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.copy_(p.to(BF).float())
+        y32 = first(net(x))
+        y16 = first(net.bfloat16()(x))
+    assert y16.dtype == BF
+    gu.check_arrays(y16.float().cpu().numpy(), y32.float().cpu().numpy(), 1e-5, 0.0, what="bf16 module",
+                    scale_rtol=1e-2)
