@@ -461,7 +461,7 @@ int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = fa
         LineDesc la, lb;
         if (!line_geometry(a, la) || !line_geometry(b, lb, false) || b.in != a.out || b.K != NC) return 0;
         if (a.N != b.N || a.GH != b.GH || a.GW != b.GW) return 0;
-        if (a.epi.res) return 0;                            // the residual tile belongs to the second epilogue
+        if (a.epi.res && b.epi.res) return 0;               // one residual tile per launch
         if (la.pstride == lb.pstride) return 0;             // same axis: not a pair
         return line_tile_bf16(NC, la.L, true);
     }

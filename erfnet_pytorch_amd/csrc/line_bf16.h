@@ -147,7 +147,10 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
     const int nblk = gridDim.x;
     const int b0 = (int)xcd_tile(blockIdx.x, nblk);
     const int s1a = d.s1[0], s1b = d.s1[1], s1c = d.s1[2];
-    const bool has_res = (PAIR ? d.epi2.res : d.epi1.res) != nullptr;
+    // One residual tensor per launch, added in the epilogue that names it: the final one, or (a pair
+    // whose first convolution closes a non_bottleneck_1d) the intermediate's.
+    const bool res_first = PAIR && d.epi1.res != nullptr;
+    const bool has_res = res_first || (PAIR ? d.epi2.res : d.epi1.res) != nullptr;
 
     // tile index -> geometry (wave-uniform)
     struct Geo { int q; unsigned base; int r0, len; };
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
     // of the residual), then a coalesced pass [mask] -> global.
     auto finish_tile = [&](const Epilogue &e, const float *sc_, const float *sh_, bf16_t *dst, const Geo &g) {
         const bool relu = e.relu != 0;
+        const bool add_res = has_res && !res_first;
 #pragma unroll
         for (int a = 0; a < WM; ++a) {
             const int px = (wp * WM + a) * 32 + l31;
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
                 const f32x4 sh = *reinterpret_cast<const f32x4 *>(sh_ + ch);
                 unsigned char *p = lds + OFF_RES + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h;
                 f32x4 rv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (has_res) rv = unpack_bf16x4(*reinterpret_cast<const u32x2 *>(p));
+                if (add_res) rv = unpack_bf16x4(*reinterpret_cast<const u32x2 *>(p));
                 f32x4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
     }
     clear_acc();
     while (true) {
-        const bf16_t *resp = (const bf16_t *)(PAIR ? d.epi2.res : d.epi1.res);
+        const bf16_t *resp = (const bf16_t *)(res_first ? d.epi1.res : (PAIR ? d.epi2.res : d.epi1.res));
         if (has_res) issue_tile(resp, g.base, g.len, OFF_RES);
         const int ntile = tile + nblk;
         const bool more = ntile < ntiles;
@@ -296,10 +300,13 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
                     const int ch = 32 * cg + 8 * gq + 4 * h;
                     const f32x4 sc = *reinterpret_cast<const f32x4 *>(cst + ch);
                     const f32x4 sh = *reinterpret_cast<const f32x4 *>(cst + NC + ch);
+                    f32x4 rv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (res_first)
+                        rv = unpack_bf16x4(*reinterpret_cast<const u32x2 *>(lds + OFF_RES + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h));
                     f32x4 v;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        v[q] = acc[a][4 * gq + q] * sc[q] + sh[q];
+                        v[q] = acc[a][4 * gq + q] * sc[q] + sh[q] + rv[q];
                         if (relu1) v[q] = fmaxf(v[q], 0.0f);
                         v[q] = live ? v[q] : 0.0f;          // positions beyond the line are conv_b's zero padding
                     }
