@@ -19,6 +19,14 @@ Design points
     parameter's buffer is granted once per step, so a second gradient of the same parameter
     (weight sharing) still accumulates through autograd; gradients therefore do NOT accumulate
     across several backward passes without ``zero_grad`` in between when this is on.
+  * A step with more than one ``backward()`` (the reference's mean-teacher loop,
+    train/main.py:377-379: ``loss_consistency.backward(retain_graph=True)`` followed by
+    ``loss_student_pred.backward()``) or with shared weights must start with
+    ``zero_grad(defer=True)``: the hooks then only record which parameters took part and
+    ``finish()`` launches every bucket after the last pass.  Without it a second gradient arriving
+    for a bucket whose all-reduce is already in flight raises instead of being lost.
+  * ``zero_grad()`` of the reducer (not the optimiser's, whose ``set_to_none`` unbinds
+    ``param.grad`` from the buckets) starts every step; ``finish()`` checks the binding.
   * The payload is small (8.2 MB of fp32 for the 20-class network), i.e. latency-bound on xGMI:
     few, large buckets beat many small ones.  Only the last bucket's all-reduce cannot overlap with
     backward, so the bucket size should leave a small remainder for it (the 128-channel stage,
@@ -50,9 +58,13 @@ class GradientReducer:
         self._pending = {}             # bucket index -> number of params still missing this step
         self._bucket_of = {}
         self._work = []
+        self._seen = set()
+        self._defer = False
+        self._grad_ptr = {}            # param -> data_ptr of its bucket slice
         self._first_step_done = False
         self._hooks = []
         self._build_buckets(self.params)
+        self._pending = {i: len(ps) for i, (_, ps) in enumerate(self._buckets)}
         for p in self.params:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -75,7 +87,7 @@ class GradientReducer:
                     off += t.numel()
 
     def _build_buckets(self, params):
-        self._buckets, self._bucket_of = [], {}
+        self._buckets, self._bucket_of, self._grad_ptr = [], {}, {}
         cur, cur_bytes = [], 0
         for p in reversed(params):
             cur.append(p)
@@ -95,6 +107,7 @@ class GradientReducer:
             if p.grad is not None:
                 view.copy_(p.grad)
             p.grad = view
+            self._grad_ptr[p] = view.data_ptr()
             if self._direct:
                 p._erf_grad_sink = (view, self)
             off += p.numel()
@@ -102,8 +115,12 @@ class GradientReducer:
         self._buckets.append((flat, list(params)))
 
     # ---------------------------------------------------------------------------------- per step
-    def zero_grad(self):
-        """Zero the bucket buffers (keeps ``param.grad`` bound to them)."""
+    def zero_grad(self, defer=False):
+        """Zero the bucket buffers (keeps ``param.grad`` bound to them) and start a step.
+
+        ``defer=True``: no all-reduce is launched from inside backward; ``finish()`` launches them all.
+        Needed when the step calls ``backward()`` more than once or shares weights between layers."""
+        self._defer = bool(defer)
         for flat, _ in self._buckets:
             flat.zero_()
         self._pending = {i: len(ps) for i, (_, ps) in enumerate(self._buckets)}
@@ -127,9 +144,17 @@ class GradientReducer:
         b = self._bucket_of.get(p)
         if b is None:
             return
+        if p in self._seen:
+            # a further gradient of this parameter in the same step (second backward pass, shared
+            # weights): fine while its bucket has not left yet, lost otherwise
+            if self._pending.get(b, 0) < 0:
+                raise RuntimeError("GradientReducer: a parameter received another gradient after its bucket's "
+                                   "all-reduce was launched (several backward passes per step, or shared "
+                                   "weights): start the step with zero_grad(defer=True)")
+            return
         self._seen.add(p)
         self._pending[b] -= 1
-        if self._pending[b] == 0 and self._first_step_done:
+        if self._pending[b] == 0 and self._first_step_done and not self._defer:
             self._launch(b)
 
     def _launch(self, b):
@@ -160,8 +185,13 @@ class GradientReducer:
             for b in range(len(self._buckets)):
                 self._launch(b)
         else:
+            for p, ptr in self._grad_ptr.items():
+                if p.grad is None or p.grad.data_ptr() != ptr:
+                    raise RuntimeError("GradientReducer: a parameter's .grad no longer points into its bucket "
+                                       "(optimizer.zero_grad(set_to_none=True)?): call reducer.zero_grad() "
+                                       "before every backward pass instead")
             for b, left in self._pending.items():
-                if left >= 0:          # bucket not launched (some parameter got no gradient this step)
+                if left >= 0:          # bucket not launched (deferred, or some parameter got no gradient)
                     self._launch(b)
         for work, flat in self._work:
             work.wait()

@@ -63,6 +63,107 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _worker_flat(rank, world, port, out_dir):
+    """flatten_parameters() + Adam on the flat buffers at world size 2, direct_write on (inert on CPU
+    tensors, but the claim/deliver bookkeeping runs), a step in which the parameters of one bucket
+    receive no gradient, and a step with two backward passes (deferred launches)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from erfnet_pytorch_amd.ddp import GradientReducer
+    model = _model()
+    red = GradientReducer(model, bucket_bytes=256 << 10, direct_write=True)
+    red.broadcast_parameters(0)
+    x, y = _batch(rank)
+    red.zero_grad()
+    torch.nn.functional.l1_loss(model(x), y).backward()
+    red.finish()
+    params = red.flatten_parameters()
+    opt = torch.optim.Adam(params, 1e-3, eps=1e-4, weight_decay=1e-6)
+    log = {}
+    # 1: ordinary step
+    red.zero_grad()
+    torch.nn.functional.l1_loss(model(x), y).backward()
+    red.finish()
+    opt.step()
+    # 2: only the encoder takes part (the decoder's buckets get no gradient and must still be reduced:
+    # zeros on both ranks, and nothing may hang)
+    red.zero_grad()
+    model.encoder(x).abs().mean().backward()
+    red.finish()
+    log["dec_grad_zero"] = all(float(p.grad.abs().max()) == 0.0 for p in model.decoder.parameters()
+                               if p.grad is not None)
+    opt.step()
+    # 3: two backward passes in one step
+    red.zero_grad(defer=True)
+    out = model(x)
+    (0.5 * out.abs().mean()).backward(retain_graph=True)
+    torch.nn.functional.l1_loss(out, y).backward()
+    red.finish()
+    log["grads3"] = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    opt.step()
+    # 4: the same two passes without defer must raise rather than lose a gradient
+    red.zero_grad()
+    out = model(x)
+    (0.5 * out.abs().mean()).backward(retain_graph=True)
+    try:
+        torch.nn.functional.l1_loss(out, y).backward()
+        log["raised"] = False
+    except RuntimeError as e:
+        log["raised"] = "defer=True" in str(e)
+    for work, _ in red._work:        # drain what step 4 launched
+        work.wait()
+    red._work = []
+    log["params"] = {k: p.detach().clone() for k, p in model.named_parameters()}
+    torch.save(log, os.path.join(out_dir, f"flat{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_parameters_unused_bucket_and_two_backward_passes_world2(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_flat, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "flat0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "flat1.pt"))
+    assert r0["dec_grad_zero"] and r1["dec_grad_zero"]
+    assert r0["raised"] and r1["raised"]
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k          # replicas stay identical
+
+    # single-process reference of the three updates on the concatenated batch
+    model = _model()
+    xs, ys = zip(*[_batch(r) for r in range(world)])
+    # per-rank losses are means over the rank's batch; their average = mean over both (equal sizes)
+    opt = torch.optim.Adam([p for p in model.parameters()], 1e-3, eps=1e-4, weight_decay=1e-6)
+    def avg(fn):
+        opt.zero_grad()
+        for x, y in zip(xs, ys):
+            (fn(x, y) / world).backward()
+    avg(lambda x, y: torch.nn.functional.l1_loss(model(x), y))
+    opt.step()
+    avg(lambda x, y: model.encoder(x).abs().mean())
+    # Adam skips parameters without a gradient; the reducer hands the decoder zeros instead, which
+    # still moves them through the moment estimates and the weight decay: apply the same zeros
+    live = set(r0["grads3"])
+    for k, p in model.named_parameters():
+        if k in live and p.grad is None:
+            p.grad = torch.zeros_like(p)
+    opt.step()
+    def two(x, y):
+        out = model(x)
+        return 0.5 * out.abs().mean() + torch.nn.functional.l1_loss(out, y)
+    avg(two)
+    for k, g in r0["grads3"].items():
+        torch.testing.assert_close(g, dict(model.named_parameters())[k].grad, rtol=2e-4, atol=1e-6)
+    opt.step()
+    for k, p in model.named_parameters():
+        torch.testing.assert_close(r0["params"][k], p.detach(), rtol=2e-4, atol=2e-6)
+
+
 @pytest.mark.timeout(300)
 def test_reducer_matches_single_process(tmp_path):
     world = 2
