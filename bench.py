@@ -11,6 +11,12 @@ train/main.py:43-51,213) of net_classification.Net(softmax_classes=20) on a synt
 6 x 3 x 512 x 1024 per GPU, fp32, inputs resident in HBM.  With N > 1 every rank holds a replica and
 the gradients are averaged over RCCL (erfnet_pytorch_amd/ddp.py); per-GPU work is fixed (weak
 scaling).  Rank 0 prints ONE JSON line.
+
+--dtype bf16 runs the same step with bf16 activations (fp32 master parameters, fp32 gradients and
+all-reduce).  At one GPU the line also carries, as extra keys, the bf16 training rate, the
+full-resolution bf16 inference time of erfnet_nobn (the reference's eval_forwardTime.py loop at
+1 x 3 x 1024 x 2048) with the bandwidth its non_bottleneck_1d blocks reach, and the ImageNet
+pre-training step of imagenet/erfnet_imagenet.py.
 """
 import argparse
 import json
@@ -25,9 +31,15 @@ import torch
 import torch.distributed as dist
 
 PER_GPU_BATCH, HEIGHT, WIDTH, CLASSES = 6, 512, 1024, 20
-# dominant kernel: the implicit-GEMM 1-D convolution at the 128-channel stage
+# dominant kernel of the fp32 step: two chained 1-D convolutions at the 128-channel stage
 DOM_C, DOM_H, DOM_W = 128, HEIGHT // 8, WIDTH // 8
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
+BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0
+# Algorithmic work per image: forward 53.2 GFLOP and 341.8 MB of fp32 block inputs + outputs; a
+# training step is three times that (backward reads a block's input, its output or mask and the
+# incoming gradient and writes the outgoing one).
+FWD_GFLOP_PER_IMAGE, FWD_MB_PER_IMAGE_F32 = 53.2, 341.8
 
 
 def parse():
@@ -40,8 +52,10 @@ def parse():
                     choices=["net_classification", "erfnet_bn"],
                     help="net_classification: the fork's training model (BatchNorm off); "
                          "erfnet_bn: eval/erfnet.ERFNet(20) with BatchNorm + Dropout2d in train mode")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage type of the activations (parameters and their gradients stay fp32)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (bf16 rates, harnesses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--forward-only", action="store_true", help="also report forward ms/img only")
     return ap.parse_args()
 
 
@@ -57,15 +71,32 @@ def logits_of(out):
     return out[0] if isinstance(out, (tuple, list)) else out
 
 
-def dominant_kernel_roofline(device, batch):
-    """Time the dominant kernel with HIP events on the stream it is launched on.
+def act_dtype(name):
+    return torch.bfloat16 if name == "bf16" else torch.float32
 
-    pair_f32_kernel<64,128> — two chained 3-tap convolutions 128 -> 128 channels over
+
+def event_time_ms(fn, device, reps, warm=5):
+    """Average milliseconds of fn() over reps calls, HIP events on the stream the kernels run on."""
+    stream = torch.cuda.current_stream(device)
+    for _ in range(warm):
+        fn()
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record(stream)
+    for _ in range(reps):
+        fn()
+    stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) / reps
+
+
+def dominant_kernel_roofline(device, batch):
+    """pair_f32_kernel<64,128> — two chained 3-tap convolutions 128 -> 128 channels over
     batch x 64 x 128 pixels in one launch (conv1x3 then conv3x1, intermediate stored as in a
-    training forward) — takes the largest share of a training step.  erf_conv_pair_forward issues
-    exactly one such launch per call (weights are packed once, outside the timed region);
+    training forward) — takes the largest share of the fp32 training step.  erf_conv_pair_forward
+    issues exactly one such launch per call (weights are packed once, outside the timed region);
     algorithmic FLOPs per launch = 2 convolutions x 2 * pixels * (3*128) * 128, algorithmic bytes =
-    input read + intermediate written + output written."""
+    input read + intermediate written + output written.  The kernel is bound by the fp32 matrix
+    rate (its HBM bound is a tenth of its run time); both fractions are reported."""
     from erfnet_pytorch_amd import functional as hipf
     g = torch.Generator(device="cpu").manual_seed(3)
     x = torch.randn(batch, DOM_C, DOM_H, DOM_W, generator=g).clamp_(min=0).to(device)
@@ -74,94 +105,160 @@ def dominant_kernel_roofline(device, batch):
     wb = (torch.randn(DOM_C, DOM_C, 3, 1, generator=g) * 0.05).to(device)
     b = torch.zeros(DOM_C, device=device)
     packed = hipf.conv_pair_pack(wa, wb)
-    stream = torch.cuda.current_stream(device)
-    reps = 50
-    for _ in range(5):
-        hipf.conv_pair(x, packed, b, b, 1, 2, 2, keep_mid=True)
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    start.record(stream)
-    for _ in range(reps):
-        hipf.conv_pair(x, packed, b, b, 1, 2, 2, keep_mid=True)
-    stop.record(stream)
-    stop.synchronize()
-    ms_per_launch = start.elapsed_time(stop) / reps
+    ms = event_time_ms(lambda: hipf.conv_pair(x, packed, b, b, 1, 2, 2, keep_mid=True), device, 50)
     pixels = batch * DOM_H * DOM_W
     flops = 2 * 2.0 * pixels * (3 * DOM_C) * DOM_C
     nbytes = 3 * pixels * DOM_C * 4
-    achieved = flops / (ms_per_launch * 1e-3) / 1e12
-    traffic = None
+    achieved = flops / (ms * 1e-3) / 1e12
+    traffic, source = None, None
     tj = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
     if os.path.exists(tj):
         try:
             traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            source = "profiles/dominant_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
+                     "not measured in this run)"
         except Exception:
             traffic = None
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": source,
             "kernel": "pair_f32_kernel<64,128> (conv1x3 + conv3x1, 128->128 channels, one launch)",
-            "us_per_launch": round(ms_per_launch * 1e3, 2), "flops_per_launch": flops,
+            "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": nbytes,
-            "hbm_bound_us": round(nbytes / 8e12 * 1e6, 2)}
+            "hbm_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "hbm_bound_us": round(nbytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2)}
 
 
-def forward_time_harness(device, batch=1, iters=20):
-    """The reference's forward-time script (eval/eval_forwardTime.py:22-58): erfnet_nobn.ERFNet(19)
-    in eval mode on a fixed torch.randn(B,3,512,1024), device synchronised around every call, the
-    first call excluded, seconds per image = t / B (the script's sleep(1) between calls dropped)."""
-    from erfnet_pytorch_amd import erfnet_nobn
-    model = erfnet_nobn.ERFNet(19).to(device).eval()
-    images = torch.randn(batch, 3, HEIGHT, WIDTH, generator=torch.Generator().manual_seed(0)).to(device)
-    times = []
-    with torch.no_grad():
-        for i in range(iters + 1):
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            model(images)
-            torch.cuda.synchronize(device)
-            if i:
-                times.append(time.perf_counter() - t0)
-    out = {"model": "erfnet_nobn.ERFNet(19)", "batch": batch, "input": "randn 3x512x1024, fp32",
-           "ms_per_img_mean": round(sum(times) / len(times) / batch * 1e3, 4),
-           "ms_per_img_min": round(min(times) / batch * 1e3, 4)}
-    # the same loop with the forward captured once into a HIP graph (one launch per call)
-    from erfnet_pytorch_amd.graphs import GraphedForward
-    graphed = GraphedForward(model, images)
+def harness_loop(call, device, batch, iters):
+    """The loop of eval/eval_forwardTime.py:40-55: device synchronised around every call, the first
+    call excluded, time per image = t / B (the script's sleep(1) dropped)."""
     times = []
     for i in range(iters + 1):
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        graphed(images)
+        call()
         torch.cuda.synchronize(device)
         if i:
             times.append(time.perf_counter() - t0)
-    out["hip_graph_ms_per_img_mean"] = round(sum(times) / len(times) / batch * 1e3, 4)
-    out["hip_graph_ms_per_img_min"] = round(min(times) / batch * 1e3, 4)
+    return round(sum(times) / len(times) / batch * 1e3, 4), round(min(times) / batch * 1e3, 4)
+
+
+def forward_time_harness(device, height, width, dtype_name, batch=1, iters=20):
+    """The reference's forward-time script (eval/eval_forwardTime.py:22-58): erfnet_nobn.ERFNet(19)
+    in eval mode on a fixed torch.randn(B,3,H,W); eager, and replayed from one HIP graph."""
+    from erfnet_pytorch_amd import erfnet_nobn
+    from erfnet_pytorch_amd.graphs import GraphedForward
+    model = erfnet_nobn.ERFNet(19).to(device).eval()
+    images = torch.randn(batch, 3, height, width, generator=torch.Generator().manual_seed(0)).to(device)
+    images = images.to(act_dtype(dtype_name))
+    out = {"model": "erfnet_nobn.ERFNet(19)", "batch": batch, "input": f"randn 3x{height}x{width}, {dtype_name}"}
+    with torch.no_grad():
+        out["ms_per_img_mean"], out["ms_per_img_min"] = harness_loop(lambda: model(images), device, batch, iters)
+    graphed = GraphedForward(model, images)
+    out["hip_graph_ms_per_img_mean"], out["hip_graph_ms_per_img_min"] = \
+        harness_loop(lambda: graphed(images), device, batch, iters)
+    gflop = FWD_GFLOP_PER_IMAGE * (height * width) / (HEIGHT * WIDTH)
+    out["hip_graph_tflops"] = round(gflop / out["hip_graph_ms_per_img_min"], 2)
     return out
 
 
+def nb1d_bandwidth(device, height, width, dtype_name):
+    """Bandwidth of the non_bottleneck_1d blocks alone, as the encoder of a height x width image
+    runs them: the five 64-channel blocks at 1/4 resolution and the eight 128-channel blocks at 1/8
+    (dilations 2,4,8,16 twice), inference, each stage as one erf_nb1d_chain_forward call, timed with
+    HIP events.  Algorithmic bytes: every block reads its input once and writes its output once."""
+    from erfnet_pytorch_amd import erfnet_blocks as eb
+    dt = act_dtype(dtype_name)
+    esz = 2 if dtype_name == "bf16" else 4
+    res = {}
+    for c, div, dils in ((64, 4, [1] * 5), (128, 8, [2, 4, 8, 16] * 2)):
+        layers = torch.nn.ModuleList([eb.non_bottleneck_1d(c, 0.0, d) for d in dils]).to(device).eval()
+        x = torch.randn(1, c, height // div, width // div, device=device).clamp_(min=0).to(dt)
+        x = x.contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            ms = event_time_ms(lambda: eb.run_layers(layers, x), device, 30)
+        px = (height // div) * (width // div)
+        nbytes = len(dils) * 2 * px * c * esz
+        flops = len(dils) * 4 * 2.0 * px * 3 * c * c
+        res[f"c{c}"] = {"blocks": len(dils), "pixels": px, "us_per_block": round(ms * 1e3 / len(dils), 2),
+                        "algorithmic_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                        "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "tflops": round(flops / (ms * 1e-3) / 1e12, 1)}
+    return res
+
+
+def train_rate(device, model_name, dtype_name, batch, steps, warmup):
+    """images/s of the training step at one GPU (no reducer): extra keys only."""
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
+    torch.manual_seed(0)
+    model = build_model(model_name).to(device).train()
+    opt = torch.optim.Adam(model.parameters(), 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
+    crit = CrossEntropyLoss2d()
+    g = torch.Generator(device="cpu").manual_seed(1000)
+    images = torch.rand(batch, 3, HEIGHT, WIDTH, generator=g).to(device).to(act_dtype(dtype_name))
+    labels = torch.randint(-1, CLASSES, (batch, HEIGHT, WIDTH), generator=g).to(device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(logits_of(model(images)), labels)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    return {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": batch,
+            "model": model_name, "dtype": dtype_name, "final_loss": round(float(loss.item()), 5)}
+
+
+def imagenet_rate(device, dtype_name, batch=256, steps=5, warmup=2):
+    """The ImageNet pre-training step of the encoder (imagenet/erfnet_imagenet.py, imagenet/main.py:
+    83-85,168-189): ERFNet(1000) with BatchNorm in train mode and Dropout2d, CrossEntropyLoss,
+    SGD(lr 0.1, momentum 0.9, weight decay 1e-4), synthetic 256 x 3 x 224 x 224 batch per GPU."""
+    from erfnet_pytorch_amd import erfnet_imagenet
+    torch.manual_seed(0)
+    model = erfnet_imagenet.ERFNet(1000).to(device).train()
+    opt = torch.optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=1e-4)
+    crit = torch.nn.CrossEntropyLoss()
+    images = torch.randn(batch, 3, 224, 224, device=device).to(act_dtype(dtype_name))
+    target = torch.randint(0, 1000, (batch,), device=device)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = crit(model(images).float(), target)
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    return {"images_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 2), "batch": batch,
+            "dtype": dtype_name, "model": "erfnet_imagenet.ERFNet(1000), BatchNorm train mode, SGD"}
+
+
 def cpu_baseline():
-    """The plain-C oracle (a port of the reference's arithmetic) timed on this host's cores:
-    forward + CrossEntropy + backward of ONE 512x1024 image (no optimiser step)."""
+    """What the reference runs on a CPU — the same modules evaluated with stock torch CPU ops
+    (forward + CrossEntropy + backward of 512x1024 images, no optimiser step) — timed on this host's
+    cores; the plain-C oracle's time for the same pass is given beside it."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
-    from oracle import oracle as orc
     model = build_model("net_classification")
-    state = {k: v.detach().numpy() for k, v in model.state_dict().items()}
     rng = np.random.default_rng(0)
     x = rng.random((1, 3, HEIGHT, WIDTH), dtype=np.float32)
     lab = rng.integers(-1, CLASSES, (1, HEIGHT, WIDTH))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
     cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
-    t0 = time.perf_counter()
-    orc.erfnet_forward(x, state, "train")
-    t_fwd = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.erfnet_train_pass(x, lab, state, "train")
-    t_train = time.perf_counter() - t0
-    out = {"value": round(1.0 / t_train, 4), "unit": "images/s", "cores": cores, "kind": "port",
-           "sample": "1 image 512x1024: forward + CrossEntropy + backward in the C oracle (OpenMP), "
-                     "no optimiser step; forward alone %.0f ms/img" % (t_fwd * 1e3)}
-    # the same arithmetic through stock torch CPU ops (what the reference itself runs on a CPU)
     model.train()
     torch.set_num_threads(cores)
     xt, lt = torch.from_numpy(x), torch.from_numpy(lab)
@@ -170,13 +267,31 @@ def cpu_baseline():
     with torch.no_grad():
         model(xt)
         t0 = time.perf_counter()
-        model(xt)
-        tf = time.perf_counter() - t0
-    t0 = time.perf_counter()
+        for _ in range(3):
+            model(xt)
+        tf = (time.perf_counter() - t0) / 3
     crit(logits_of(model(xt)), lt).backward()
-    tt = time.perf_counter() - t0
-    out["torch_cpu_path"] = {"fwd_ms_per_img": round(tf * 1e3, 1), "train_images_per_s": round(1.0 / tt, 3),
-                             "threads": cores}
+    n = 0
+    t0 = time.perf_counter()
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 40):
+        model.zero_grad(set_to_none=True)
+        crit(logits_of(model(xt)), lt).backward()
+        n += 1
+    tt = (time.perf_counter() - t0) / n
+    out = {"value": round(1.0 / tt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+           "sample": "%d passes over one 512x1024 image: forward + CrossEntropy + backward of "
+                     "net_classification.Net(20) through stock torch CPU ops on the drop-in modules "
+                     "(the arithmetic the reference runs on a CPU), no optimiser step; forward alone "
+                     "%.0f ms/img" % (n, tf * 1e3)}
+    try:
+        from oracle import oracle as orc
+        state = {k: v.detach().numpy() for k, v in model.state_dict().items()}
+        t0 = time.perf_counter()
+        orc.erfnet_train_pass(x, lab, state, "train")
+        out["c_oracle_images_per_s"] = round(1.0 / (time.perf_counter() - t0), 4)
+    except Exception as e:                                  # the oracle is the checker, not the baseline
+        out["c_oracle_images_per_s"] = None
+        out["c_oracle_error"] = str(e)[:200]
     return out
 
 
@@ -185,13 +300,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("ERFNET_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        sys.exit("bench.py needs a GPU (the HIP kernels are the only compute path for the measured step)")
+    if world > 1 and backend == "nccl" and (world > ndev or local_rank >= ndev):
+        # two ranks sharing one device hang inside RCCL's first collective: refuse instead
+        sys.exit(f"bench.py: WORLD_SIZE {world} (LOCAL_RANK {local_rank}) but only {ndev} GPU(s) are visible; "
+                 f"RCCL needs one device per rank")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(os.environ.get("ERFNET_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {world}; using {world}", file=sys.stderr)
-    local_rank %= max(torch.cuda.device_count(), 1)     # rehearsals with more ranks than GPUs share devices
+    local_rank %= ndev                  # (only reachable with a non-RCCL rehearsal backend)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -209,7 +332,7 @@ def main():
     crit = CrossEntropyLoss2d()       # train/main.py:186-188
 
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    images = torch.rand(args.batch, 3, HEIGHT, WIDTH, generator=g).to(device)
+    images = torch.rand(args.batch, 3, HEIGHT, WIDTH, generator=g).to(device).to(act_dtype(args.dtype))
     labels = torch.randint(-1, CLASSES, (args.batch, HEIGHT, WIDTH), generator=g).to(device)
 
     # Set-up pass (no update): one backward tells the reducer which parameters take part; they are
@@ -253,23 +376,14 @@ def main():
     assert _lib.launch_count() > launches0, "the HIP kernels did not run"
     final_loss = float(loss.item())
 
-    fwd_ms = None
-    if rank == 0:
-        model.eval()
-        with torch.no_grad():
-            for _ in range(2):
-                model(images)
-            torch.cuda.synchronize(device)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                model(images)
-            torch.cuda.synchronize(device)
-            fwd_ms = (time.perf_counter() - t1) / 5 / args.batch * 1e3
-
-    h1 = forward_time_harness(device) if rank == 0 else None
-
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
+        ms_step = elapsed / args.steps * 1e3
+        esz = 0.5 if args.dtype == "bf16" else 1.0
+        step_gflop = 3 * FWD_GFLOP_PER_IMAGE * args.batch
+        step_mb = 3 * FWD_MB_PER_IMAGE_F32 * esz * args.batch
+        gpu = torch.cuda.get_device_name(device)
+        bn = "BatchNorm off" if args.model == "net_classification" else "BatchNorm (train mode) + Dropout2d"
         rec = {
             "metric": "images/sec train (512x1024, 20cls)",
             "value": round(value, 2),
@@ -277,25 +391,46 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "ms_per_step": round(ms_step, 3),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic (uniform [0,1) images, labels in [-1,20), random-init weights)",
-            "config": {"workload": "1xMI355X training, batch=6, 512x1024, 20 classes, fp32, "
-                                   "encoder+decoder (BASELINE configs[1])",
+            "config": {"workload": f"{world}x{gpu} training, batch={args.batch} per GPU, {HEIGHT}x{WIDTH}, "
+                                   f"{CLASSES} classes, {args.dtype}, encoder+decoder ({args.model}, {bn})"
+                                   + (" [BASELINE configs[1]]" if (world == 1 and args.batch == 6 and
+                                                                  args.dtype == "f32" and
+                                                                  args.model == "net_classification") else ""),
                        "model": args.model, "per_gpu_batch": args.batch,
                        "global_batch": world * args.batch,
                        "step": "forward + CrossEntropy(ignore -1) + backward + Adam(lr 1e-4, eps 1e-4, wd 1e-6)",
                        "parallelism": f"dp{world}",
                        "grad_buckets_bytes": reducer.bucket_sizes},
-            "fwd_ms_per_img": round(fwd_ms, 4),
-            "forward_time_harness": h1,
             "final_loss": round(final_loss, 5),
+            # whole step against both rooflines (algorithmic work of the blocks / measured step time)
+            "step_tflops": round(step_gflop / ms_step, 2),
+            "step_algorithmic_gbs": round(step_mb / ms_step, 1),
+            "step_hbm_frac": round(step_mb / ms_step / HBM_PEAK_GBS, 4),
         }
         if world == 1:
+            del model, opt, params, reducer
+            torch.cuda.empty_cache()
             rec["roofline"] = dominant_kernel_roofline(device, args.batch)
+            if not args.no_extras:
+                other = "bf16" if args.dtype == "f32" else "f32"
+                rec["train_other_dtype"] = train_rate(device, args.model, other, args.batch, 10, 3)
+                rec["forward_time_harness"] = forward_time_harness(device, HEIGHT, WIDTH, "f32")
+                # BASELINE configs[2]: eval_forwardTime.py path, erfnet_nobn, bf16, 1024x2048
+                full = forward_time_harness(device, 2 * HEIGHT, 2 * WIDTH, "bf16")
+                full["nb1d"] = nb1d_bandwidth(device, 2 * HEIGHT, 2 * WIDTH, "bf16")
+                full["f32_ms_per_img_min"] = forward_time_harness(device, 2 * HEIGHT, 2 * WIDTH, "f32",
+                                                                  iters=10)["ms_per_img_min"]
+                rec["fullres_inference_bf16"] = full
+                rec["train_erfnet_bn"] = train_rate(device, "erfnet_bn", args.dtype, args.batch, 8, 3)
+                # BASELINE configs[4] per GPU: the ImageNet pre-training step of the encoder
+                rec["imagenet_pretrain"] = {"f32": imagenet_rate(device, "f32"),
+                                            "bf16": imagenet_rate(device, "bf16")}
             if not args.no_cpu_baseline:
                 rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)

@@ -22,10 +22,7 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __builtin_bit_ca
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v)
 {
-    bf16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-    return __builtin_bit_cast(u32x2, o);
+    return __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));      // two v_cvt_pk_bf16_f32
 }
 __device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 u)
 {

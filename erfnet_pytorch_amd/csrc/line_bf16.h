@@ -24,6 +24,7 @@
 // one rounding to bf16 (the intermediate is rounded once, after its ReLU).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 struct LineDesc {
     const bf16_t *in;
@@ -37,6 +38,9 @@ struct LineDesc {
     int pstride;                // pixel-index distance between neighbours on a line
     int qstride;                // pixel-index distance between the bases of neighbouring lines
     int s1[3], s2[3];
+#ifdef ERF_LINE_STAMPS
+    unsigned long long *stamps;     // diagnostic build only: [block][32] shader-clock stamps of wave 0
+#endif
 };
 
 // Weight fragments: wp[tap][k16 step s][channel group cg][lane][8] with
@@ -80,6 +84,16 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_byte_ad
                                      (void __attribute__((address_space(3))) *)(uintptr_t)lds_byte_addr, 16, 0, 0);
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter, i.e. it would wait for the output stores of the tile just finished and for the DMA of the
+// next tile, which are meant to stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // bf16 patterns: zero the elements of v whose mask element is not > 0
 __device__ __forceinline__ u32x4 mask_bf16x8(u32x4 v, u32x4 m)
 {
@@ -114,33 +128,21 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef ERF_LINE_STAMPS
+    int stamp_i = 0;
+#define LINE_STAMP()                                                                               \
+    do {                                                                                           \
+        if (d.stamps && tid == 0 && stamp_i < 32)                                                  \
+            d.stamps[(size_t)blockIdx.x * 32 + stamp_i++] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+#else
+#define LINE_STAMP() do {} while (0)
+#endif
+    LINE_STAMP();
     const int cg = wave % GC, wp = wave / GC;
     const int l31 = lane & 31, h = lane >> 5;
     // LDS byte address of the array (the DMA's destination is an LDS address, not a generic pointer)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
-
-    // ---- per-block set-up: epilogue constants, zero row, weights into registers
-    for (int c = tid; c < NC; c += 256) {
-        float sc, sh;
-        epi_channel_affine(d.epi1, c, sc, sh);
-        cst[c] = sc; cst[NC + c] = sh;
-        if constexpr (PAIR) {
-            epi_channel_affine(d.epi2, c, sc, sh);
-            cst[2 * NC + c] = sc; cst[3 * NC + c] = sh;
-        }
-    }
-    if constexpr (PAIR)
-        for (int i = tid; i < PITCH / 4; i += 256) reinterpret_cast<unsigned *>(lds + OFF_MID + T)[i] = 0u;
-
-    bf16x8 w1[3][KS], w2[PAIR ? 3 : 1][PAIR ? KS : 1];
-#pragma unroll
-    for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const size_t f = ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8;
-            w1[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + f);
-            if constexpr (PAIR) w2[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp2 + f);
-        }
 
     const int L = d.L;
     const int ntiles = d.nlines * d.segs;
@@ -180,57 +182,6 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
         }
     };
 
-    f32x16 acc[WM];
-    auto clear_acc = [&]() {
-#pragma unroll
-        for (int a = 0; a < WM; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
-    };
-
-    // Final epilogue of a tile: v = acc*sc + sh [+ res] -> [relu] -> bf16 into the RES tile (in place
-    // of the residual), then a coalesced pass [mask] -> global.
-    auto finish_tile = [&](const Epilogue &e, const float *sc_, const float *sh_, bf16_t *dst, const Geo &g) {
-        const bool relu = e.relu != 0;
-        const bool add_res = has_res && !res_first;
-#pragma unroll
-        for (int a = 0; a < WM; ++a) {
-            const int px = (wp * WM + a) * 32 + l31;
-            const int sw = line_swz<NC>(px);
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int ch = 32 * cg + 8 * gq + 4 * h;
-                const f32x4 sc = *reinterpret_cast<const f32x4 *>(sc_ + ch);
-                const f32x4 sh = *reinterpret_cast<const f32x4 *>(sh_ + ch);
-                unsigned char *p = lds + OFF_RES + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h;
-                f32x4 rv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                if (add_res) rv = unpack_bf16x4(*reinterpret_cast<const u32x2 *>(p));
-                f32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = acc[a][4 * gq + q] * sc[q] + sh[q] + rv[q];
-                    if (relu) v[q] = fmaxf(v[q], 0.0f);
-                }
-                *reinterpret_cast<u32x2 *>(p) = pack_bf16x4(v);
-            }
-        }
-        __syncthreads();
-        const bf16_t *mk = (const bf16_t *)e.mask;
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            const int slot = p * 256 + tid;
-            const int r = slot / CPR, pc = slot % CPR;
-            const int c = pc ^ line_swz<NC>(r);
-            if (r < g.len) {
-                u32x4 v = *reinterpret_cast<const u32x4 *>(lds + OFF_RES + slot * 16);
-                const size_t off = (size_t)(g.base + (unsigned)(r * d.pstride)) * NC + c * 8;
-                if (mk) v = mask_bf16x8(v, *reinterpret_cast<const u32x4 *>(mk + off));
-                *reinterpret_cast<u32x4 *>(dst + off) = v;
-            }
-        }
-        __syncthreads();
-    };
-
     int tile = b0;
     if (tile >= ntiles) return;
     Geo g = geo(tile);
@@ -241,7 +192,177 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
         while (!tap_valid(g, t)) ++t;        // the centre tap is always valid
         issue_tile(d.in, g.base + (unsigned)(tap_shift(t) * d.qstride), g.len, OFF_TAP);
     }
+    // ---- per-block set-up, behind the first tile's DMA: weights into registers, epilogue constants,
+    // zero row
+    bf16x8 w1[3][KS], w2[PAIR ? 3 : 1][PAIR ? KS : 1];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const size_t f = ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8;
+            w1[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + f);
+            if constexpr (PAIR) w2[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp2 + f);
+        }
+
+    for (int c = tid; c < NC; c += 256) {
+        float sc, sh;
+        epi_channel_affine(d.epi1, c, sc, sh);
+        cst[c] = sc; cst[NC + c] = sh;
+        if constexpr (PAIR) {
+            epi_channel_affine(d.epi2, c, sc, sh);
+            cst[2 * NC + c] = sc; cst[3 * NC + c] = sh;
+        }
+    }
+    if constexpr (PAIR)
+        for (int i = tid; i < PITCH / 4; i += 256) reinterpret_cast<unsigned *>(lds + OFF_MID + T)[i] = 0u;
+
+    f32x16 acc[WM];
+    auto clear_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    };
+
+    // MFMAs of one tap: operand rows rowp[a] (+ swizzle term x4[a]) against the weight fragments w[s].
+    // The fragments of k-step s+1 are read while the MFMAs of step s run (the compiler, left alone,
+    // waits for every read right in front of its MFMA: with one wave per SIMD nothing else hides the
+    // LDS latency).
+    auto mma_tap = [&](const bf16x8 (&w)[KS], const unsigned char *const (&rowp)[WM], const unsigned (&x4)[WM]) {
+        constexpr int D = WM >= 4 ? 2 : 3;      // fragment sets: reads run D - 1 k-steps ahead of their MFMAs
+        bf16x8 xf[D][WM];
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s)
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+                xf[s][a] = *reinterpret_cast<const bf16x8 *>(rowp[a] + ((unsigned)(s << 5) ^ x4[a]));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + D - 1 < KS) {
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+                    xf[(s + D - 1) % D][a] = *reinterpret_cast<const bf16x8 *>(rowp[a] + ((unsigned)((s + D - 1) << 5) ^ x4[a]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], xf[s % D][a], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // Coalesced pass over a finished LDS tile (bf16, swizzled): [mask by a global tensor, written back
+    // to the tile when `keep`] -> [global store].  Four 16-byte chunks per thread are in flight at a time.
+    auto sweep_tile = [&](int lds_off, const bf16_t *mk, bf16_t *dst, bool keep, const Geo &g) {
+        constexpr int B = PASSES % 4 == 0 ? 4 : (PASSES % 2 == 0 ? 2 : 1);
+#pragma unroll
+        for (int p0 = 0; p0 < PASSES; p0 += B) {
+            u32x4 v[B], m[B];
+            size_t off[B];
+            bool live[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                const int slot = (p0 + i) * 256 + tid;
+                const int r = slot / CPR, pc = slot % CPR;
+                const int c = pc ^ line_swz<NC>(r);
+                live[i] = r < g.len;
+                const int rr = live[i] ? r : g.len - 1;
+                off[i] = (size_t)(g.base + (unsigned)(rr * d.pstride)) * NC + c * 8;
+                v[i] = *reinterpret_cast<const u32x4 *>(lds + lds_off + slot * 16);
+            }
+            if (mk) {
+#pragma unroll
+                for (int i = 0; i < B; ++i) m[i] = *reinterpret_cast<const u32x4 *>(mk + off[i]);
+#pragma unroll
+                for (int i = 0; i < B; ++i) v[i] = mask_bf16x8(v[i], m[i]);
+                if (keep) {
+#pragma unroll
+                    for (int i = 0; i < B; ++i) *reinterpret_cast<u32x4 *>(lds + lds_off + ((p0 + i) * 256 + tid) * 16) = v[i];
+                }
+            }
+            if (dst) {
+#pragma unroll
+                for (int i = 0; i < B; ++i)
+                    if (live[i]) *reinterpret_cast<u32x4 *>(dst + off[i]) = v[i];
+            }
+        }
+    };
+
+    // Accumulators -> bf16 tile in LDS: v = acc*sc + sh [+ res tile] -> [relu] -> [zero beyond the line].
+    // The per-channel constants and a pixel tile's residual quads are read as batches ahead of the
+    // arithmetic.
+    // (the three switches are compile-time: evaluated per element they cost more instructions than
+    // the arithmetic itself, and with one wave per SIMD nothing overlaps an epilogue)
+    auto store_acc_t = [&](auto relu_t, auto scale_t, auto res_t, const float *sc_, const float *sh_, bool zero_dead,
+                           int dst_off, const Geo &g) {
+        constexpr bool RELU = decltype(relu_t)::value, SCALE = decltype(scale_t)::value, RES = decltype(res_t)::value;
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const bool ragged = zero_dead && g.len < BM;          // wave-uniform
+        f32x4 sc[4], sh[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch = 32 * cg + 8 * gq + 4 * h;
+            if (SCALE) sc[gq] = *reinterpret_cast<const f32x4 *>(sc_ + ch);
+            sh[gq] = *reinterpret_cast<const f32x4 *>(sh_ + ch);
+        }
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+            const int px = (wp * WM + a) * 32 + l31;
+            const int sw = line_swz<NC>(px);
+            u32x2 rr[4];
+            if (RES) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    rr[gq] = *reinterpret_cast<const u32x2 *>(lds + OFF_RES + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h);
+            }
+            u32x2 pk[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 v = f32x4{acc[a][4 * gq], acc[a][4 * gq + 1], acc[a][4 * gq + 2], acc[a][4 * gq + 3]};
+                // packed fp32 arithmetic (two elements per instruction); without BatchNorm the scale is 1
+                if (SCALE) v = v * sc[gq] + sh[gq];
+                else v = v + sh[gq];
+                if (RES) v = v + unpack_bf16x4(rr[gq]);
+                pk[gq] = pack_bf16x4(v);
+                // ReLU on the bf16 patterns: as signed 16-bit integers every negative value is < 0
+                if (RELU) pk[gq] = __builtin_bit_cast(u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, pk[gq]), s16x4{0, 0, 0, 0}));
+            }
+            if (ragged) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) pk[gq] = px < g.len ? pk[gq] : u32x2{0u, 0u};
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<u32x2 *>(lds + dst_off + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h) = pk[gq];
+        }
+    };
+    auto store_acc = [&](const Epilogue &e, const float *sc_, const float *sh_, bool add_res, bool zero_dead,
+                         int dst_off, const Geo &g) {
+        using T1 = std::true_type;
+        using T0 = std::false_type;
+        const int key = (e.relu ? 4 : 0) | (e.bn.on ? 2 : 0) | (add_res ? 1 : 0);
+        switch (key) {          // wave-uniform
+        case 0: store_acc_t(T0{}, T0{}, T0{}, sc_, sh_, zero_dead, dst_off, g); break;
+        case 1: store_acc_t(T0{}, T0{}, T1{}, sc_, sh_, zero_dead, dst_off, g); break;
+        case 2: store_acc_t(T0{}, T1{}, T0{}, sc_, sh_, zero_dead, dst_off, g); break;
+        case 3: store_acc_t(T0{}, T1{}, T1{}, sc_, sh_, zero_dead, dst_off, g); break;
+        case 4: store_acc_t(T1{}, T0{}, T0{}, sc_, sh_, zero_dead, dst_off, g); break;
+        case 5: store_acc_t(T1{}, T0{}, T1{}, sc_, sh_, zero_dead, dst_off, g); break;
+        case 6: store_acc_t(T1{}, T1{}, T0{}, sc_, sh_, zero_dead, dst_off, g); break;
+        default: store_acc_t(T1{}, T1{}, T1{}, sc_, sh_, zero_dead, dst_off, g); break;
+        }
+    };
+
+    // Final epilogue of a tile: accumulators (+ residual) -> RES tile (in place of the residual), then
+    // a coalesced pass [mask] -> global.
+    auto finish_tile = [&](const Epilogue &e, const float *sc_, const float *sh_, bf16_t *dst, const Geo &g) {
+        store_acc(e, sc_, sh_, has_res && !res_first, false, OFF_RES, g);
+        lds_barrier();
+        sweep_tile(OFF_RES, (const bf16_t *)e.mask, dst, false, g);
+        lds_barrier();          // the RES tile may be refilled; the stores stay in flight
+    };
+
     clear_acc();
+    LINE_STAMP();       // 1: set-up issued (weights, constants, first tap)
     while (true) {
         const bf16_t *resp = (const bf16_t *)(res_first ? d.epi1.res : (PAIR ? d.epi2.res : d.epi1.res));
         if (has_res) issue_tile(resp, g.base, g.len, OFF_RES);
@@ -258,8 +379,11 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
             // valid tap of the block's next tile
             int nt = t + 1;
             while (nt < 3 && !tap_valid(g, nt)) ++nt;
+            // the tap's DMA (and everything older on the vector-memory counter) has landed in this
+            // wave; after the barrier, in all of them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            lds_barrier();
+            LINE_STAMP();   // tap landed
             if (nt < 3) {
                 issue_tile(d.in, g.base + (unsigned)(tap_shift(nt) * d.qstride), g.len, OFF_TAP + ((seq + 1) & 1) * T);
             } else if (more) {
@@ -267,6 +391,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
                 while (!tap_valid(gn, ft)) ++ft;
                 issue_tile(d.in, gn.base + (unsigned)(tap_shift(ft) * d.qstride), gn.len, OFF_TAP + ((seq + 1) & 1) * T);
             }
+            LINE_STAMP();   // next DMA issued
             const unsigned char *tb = lds + OFF_TAP + (seq & 1) * T;
             const unsigned char *rowp[WM];
             unsigned x4[WM];
@@ -276,63 +401,22 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
                 rowp[a] = tb + px * PITCH;
                 x4[a] = (unsigned)((line_swz<NC>(px) ^ h) << 4);
             }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                bf16x8 xf[WM];
-#pragma unroll
-                for (int a = 0; a < WM; ++a) xf[a] = *reinterpret_cast<const bf16x8 *>(rowp[a] + ((unsigned)(s << 5) ^ x4[a]));
-#pragma unroll
-                for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[t][s], xf[a], acc[a], 0, 0, 0);
-            }
+            mma_tap(w1[t], rowp, x4);
+            LINE_STAMP();   // tap MFMAs done
             ++seq;
         }
 
         if constexpr (PAIR) {
             // -------------------------------------------------------- intermediate tile -> LDS (bf16)
-            const bool relu1 = d.epi1.relu != 0;
-#pragma unroll
-            for (int a = 0; a < WM; ++a) {
-                const int px = (wp * WM + a) * 32 + l31;
-                const int sw = line_swz<NC>(px);
-                const bool live = px < g.len;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int ch = 32 * cg + 8 * gq + 4 * h;
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(cst + ch);
-                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(cst + NC + ch);
-                    f32x4 rv = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (res_first)
-                        rv = unpack_bf16x4(*reinterpret_cast<const u32x2 *>(lds + OFF_RES + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h));
-                    f32x4 v;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v[q] = acc[a][4 * gq + q] * sc[q] + sh[q] + rv[q];
-                        if (relu1) v[q] = fmaxf(v[q], 0.0f);
-                        v[q] = live ? v[q] : 0.0f;          // positions beyond the line are conv_b's zero padding
-                    }
-                    *reinterpret_cast<u32x2 *>(lds + OFF_MID + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h) = pack_bf16x4(v);
-                }
-            }
+            // (positions beyond the line are conv_b's zero padding)
+            store_acc(d.epi1, cst, cst + NC, res_first, true, OFF_MID, g);
             clear_acc();
-            __syncthreads();
+            lds_barrier();
+            LINE_STAMP();   // intermediate in LDS
             const bf16_t *mk1 = (const bf16_t *)d.epi1.mask;
             if (d.mid || mk1) {                              // wave-uniform
-#pragma unroll
-                for (int p = 0; p < PASSES; ++p) {
-                    const int slot = p * 256 + tid;
-                    const int r = slot / CPR, pc = slot % CPR;
-                    const int c = pc ^ line_swz<NC>(r);
-                    if (r < g.len) {
-                        u32x4 v = *reinterpret_cast<const u32x4 *>(lds + OFF_MID + slot * 16);
-                        const size_t off = (size_t)(g.base + (unsigned)(r * d.pstride)) * NC + c * 8;
-                        if (mk1) {
-                            v = mask_bf16x8(v, *reinterpret_cast<const u32x4 *>(mk1 + off));
-                            *reinterpret_cast<u32x4 *>(lds + OFF_MID + slot * 16) = v;
-                        }
-                        if (d.mid) *reinterpret_cast<u32x4 *>(d.mid + off) = v;
-                    }
-                }
-                if (mk1) __syncthreads();
+                sweep_tile(OFF_MID, mk1, d.mid, true, g);
+                if (mk1) lds_barrier();
             }
             // -------------------------------------------------------- conv_b: operand = intermediate tile
 #pragma unroll
@@ -347,20 +431,15 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
                     rowp[a] = lds + OFF_MID + rz * PITCH;
                     x4[a] = (unsigned)((line_swz<NC>(rz) ^ h) << 4);
                 }
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    bf16x8 xf[WM];
-#pragma unroll
-                    for (int a = 0; a < WM; ++a) xf[a] = *reinterpret_cast<const bf16x8 *>(rowp[a] + ((unsigned)(s << 5) ^ x4[a]));
-#pragma unroll
-                    for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[t][s], xf[a], acc[a], 0, 0, 0);
-                }
+                mma_tap(w2[t], rowp, x4);
             }
+            LINE_STAMP();   // conv_b MFMAs done
             finish_tile(d.epi2, cst + 2 * NC, cst + 3 * NC, d.out, g);
         } else {
             finish_tile(d.epi1, cst, cst + NC, d.out, g);
         }
         clear_acc();
+        LINE_STAMP();       // tile stored
         if (!more) break;
         tile = ntile;
         g = gn;

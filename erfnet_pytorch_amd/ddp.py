@@ -136,7 +136,11 @@ class GradientReducer:
         return True
 
     def _delivered(self, p):
-        self._on_grad(p)
+        # The kernel's write into the bucket slice has been enqueued.  Nothing is counted here: autograd
+        # still runs the parameter's accumulate node (with an undefined gradient) and with it the
+        # post-accumulate hook, which is where every gradient is counted once.  Should a torch version
+        # skip the hook for undefined gradients, the bucket is simply launched from finish().
+        pass
 
     def _on_grad(self, p):
         if self.world == 1 and self._first_step_done and not self._always:

@@ -43,7 +43,10 @@ class Classifier(nn.Module):
         self.linear = nn.Linear(128, num_classes)
 
     def forward(self, input):
-        return self.linear(input.reshape(input.size(0), 128))
+        t = input.reshape(input.size(0), 128)
+        # bf16 activations with fp32 master parameters: the 128 -> classes product runs in the
+        # parameters' type
+        return self.linear(t.to(self.linear.weight.dtype))
 
 
 class ERFNet(nn.Module):
