@@ -8,6 +8,7 @@
 #include "pair.h"
 #include "line_bf16.h"
 #include "wgrad_line.h"
+#include "wgrad_line_bf16.h"
 #include "loss_kernels.h"
 #include "metric_kernels.h"
 
@@ -683,8 +684,11 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     }
     const int max_split = nsplit;
     dim3 grid((unsigned)max_split, jtiles, n);
-    if (NC == 128) BY_DT(dd[0].dt, (wgrad_line_kernel<128, 1, 2, 4, 2, 1, T><<<grid, 512, 0, st>>>(wb)));
-    else BY_DT(dd[0].dt, (wgrad_line_kernel<64, 1, 1, 2, 2, 3, T><<<grid, 256, 0, st>>>(wb)));
+    if (dd[0].dt) {         // bf16 tensors: bf16 MFMA, fragments through the transposing LDS read
+        if (NC == 128) wgrad_line_bf16_kernel<128, 1, 2, 4, 2, 1><<<grid, 512, 0, st>>>(wb);
+        else wgrad_line_bf16_kernel<64, 1, 1, 2, 2, 3><<<grid, 256, 0, st>>>(wb);
+    } else if (NC == 128) wgrad_line_kernel<128, 1, 2, 4, 2, 1, float><<<grid, 512, 0, st>>>(wb);
+    else wgrad_line_kernel<64, 1, 1, 2, 2, 3, float><<<grid, 256, 0, st>>>(wb);
     CHECK_LAUNCH("wgrad_line_kernel");
     // the slab carries the column sums of G in bias row 0 only
     return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps ? 1u : 0u, st);

@@ -240,3 +240,68 @@ def test_bf16_module_matches_bf16_activations_with_fp32_module():
     assert y16.dtype == BF
     gu.check_arrays(y16.float().cpu().numpy(), y32.float().cpu().numpy(), 1e-5, 0.0, what="bf16 module",
                     scale_rtol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+# Strict backward: erf_nb1d_backward_bf16 through the raw C ABI, fed the saved activations of an
+# fp64 forward on the bf16-rounded operands, against an fp64 backward that rounds where the kernels
+# round (every gradient tensor handed from one convolution to the next is stored as bf16).  The
+# ReLU masks are pinned by the shared activations, so the comparison is elementwise.
+def _conv_bwd(inp, w, g, axis, dil):
+    """gradients of out = conv1d(inp, w) w.r.t. inp and w (fp64); w [C,C,3]"""
+    w4 = w[:, :, :, None] if axis == 0 else w[:, :, None, :]
+    pad, dl = ((dil, 0), (dil, 1)) if axis == 0 else ((0, dil), (1, dil))
+    dinp = torch.nn.grad.conv2d_input(inp.shape, w4, g, padding=pad, dilation=dl)
+    dw = torch.nn.grad.conv2d_weight(inp, w4.shape, g, padding=pad, dilation=dl)
+    return dinp, dw.reshape(w.shape), g.sum(dim=(0, 2, 3))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("c,h,w,dil,flags", [(64, 40, 72, 2, 0), (128, 40, 64, 4, 2), (128, 70, 24, 16, 0),
+                                             (64, 130, 40, 1, 2)])
+def test_nb1d_backward_bf16_strict(c, h, w, dil, flags):
+    from erfnet_pytorch_amd import _lib
+    lib = _lib.lib()
+    n = 2
+    tag = f"bf16bwd.{c}.{h}.{w}.{dil}"
+    x = _rb(torch.relu(torch.as_tensor(gu.det_normal(tag + ".x", (n, c, h, w)))))
+    ws = [_rb(torch.as_tensor(gu.det_normal(tag + f".w{i}", (c, c, 3))) * (1.0 / (3 * c) ** 0.5)) for i in range(4)]
+    bs = [torch.as_tensor(gu.det_normal(tag + f".b{i}", (c,))).double() * 0.1 for i in range(4)]
+    gy = _rb(torch.as_tensor(gu.det_normal(tag + ".gy", (n, c, h, w))))
+    axes, dils = (0, 1, 0, 1), (1, 1, dil, dil)
+    # forward with the kernels' rounding points
+    t1 = _rb(torch.relu(_conv1d(x, ws[0], bs[0], 0, 1)))
+    t2 = _rb(torch.relu(_conv1d(t1, ws[1], bs[1], 1, 1)))
+    t3 = _rb(torch.relu(_conv1d(t2, ws[2], bs[2], 0, dil)))
+    y = _rb(torch.relu(_conv1d(t3, ws[3], bs[3], 1, dil) + x))
+    # backward
+    g4 = gy * (y > 0)
+    d3, dw3, db3 = _conv_bwd(t3, ws[3], g4, 1, dil)
+    gb = _rb(d3 * (t3 > 0))
+    d2, dw2, db2 = _conv_bwd(t2, ws[2], gb, 0, dil)
+    ga = _rb(d2 * (t2 > 0))
+    d1, dw1, db1 = _conv_bwd(t1, ws[1], ga, 1, 1)
+    g1 = _rb(d1 * (t1 > 0))
+    d0, dw0, db0 = _conv_bwd(x, ws[0], g1, 0, 1)
+    dx = d0 + g4
+    if flags & 2:
+        dx = dx * (x > 0)
+    ref_dw, ref_db = [dw0, dw1, dw2, dw3], [db0, db1, db2, db3]
+
+    dev = lambda t_: _nhwc(t_.to(DEV).to(BF))
+    xd, yd, t1d, t2d, t3d, gyd = (dev(t_) for t_ in (x, y, t1, t2, t3, gy))
+    wd = [t_.to(DEV).float().contiguous() for t_ in ws]
+    dxd = torch.empty_like(xd)
+    dwd = [torch.empty(c, c, 3, device=DEV) for _ in range(4)]
+    dbd = [torch.empty(c, device=DEV) for _ in range(4)]
+    arr = lambda ts: (C.c_void_p * len(ts))(*[None if t_ is None else t_.data_ptr() for t_ in ts])
+    ws_buf = torch.empty(int(lib.erf_workspace_bytes(n * h * w, c)), dtype=torch.uint8, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.erf_nb1d_backward_bf16(_ptr(xd), arr(wd), None, None, None, dil, _ptr(yd),
+                                          arr([t1d, None, t2d, t3d, None]), _ptr(gyd), _ptr(dxd), arr(dwd), arr(dbd),
+                                          None, None, n, c, h, w, flags, _ptr(ws_buf), ws_buf.numel(), st))
+    torch.cuda.synchronize()
+    _check(dxd, dx, "dx", tol=2.0 ** -6)           # three chained roundings of the gradient
+    for i in range(4):
+        _check(dwd[i], ref_dw[i], f"dw{i}", tol=2e-3)
+        _check(dbd[i], ref_db[i], f"db{i}", tol=2e-3)
