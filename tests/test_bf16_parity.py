@@ -305,3 +305,24 @@ def test_nb1d_backward_bf16_strict(c, h, w, dil, flags):
     for i in range(4):
         _check(dwd[i], ref_dw[i], f"dw{i}", tol=2e-3)
         _check(dbd[i], ref_db[i], f"db{i}", tol=2e-3)
+
+
+@pytest.mark.timeout(300)
+def test_fullres_1024x2048_erfnet_nobn_bf16():
+    """BASELINE configs[2]: erfnet_nobn.ERFNet(19), bf16, 1 x 3 x 1024 x 2048 against the fp32
+    golden of the reference: 1e-2 of the logits' scale (tail of at most 1e-3 of the elements within
+    3e-2), identical arg-max away from ties."""
+    extra = gu.load_npz("extra.npz")
+    key = "eval_erfnet_nobn_19"
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    x = _t(gu.det_uniform("net.x_fullres", (1, 3, 1024, 2048), 0.0, 1.0)).to(BF)
+    with torch.no_grad():
+        y = net(x)
+    assert y.dtype == BF
+    y = y.float().cpu().numpy()
+    gu.check(extra, "fullres/y", y, 1e-5, 0.0, what="fullres bf16 logits", scale_rtol=1e-2, outlier_frac=1e-3,
+             outlier_rtol=3e-2)
+    scale = float(extra["fullres/y#stat"][2])
+    ok = extra["fullres/margin_s2"].astype(np.float32) > 2e-2 * scale
+    assert ok.mean() > 0.3
+    assert np.array_equal(y.argmax(1)[:, ::2, ::2].astype(np.uint8)[ok], extra["fullres/argmax_s2"][ok])
