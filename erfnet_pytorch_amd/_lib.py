@@ -102,6 +102,12 @@ _PROTOS = {
     "erf_cross_entropy_forward_static": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ll, vp]),
     "erf_accuracy_counts": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
     "erf_iou_add_batch": (C.c_int, [vp, vp, ll, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
+    "erf_masked_loss_forward": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_float, vp, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, vp, C.c_size_t, vp]),
+    "erf_masked_loss_backward": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "erf_mse_mean_forward": (C.c_int, [vp, vp, ll, vp, vp, C.c_size_t, vp]),
+    "erf_mse_mean_backward": (C.c_int, [vp, vp, vp, vp, ll, vp]),
     "erf_cross_entropy_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                              C.c_int, ll, vp]),
 }

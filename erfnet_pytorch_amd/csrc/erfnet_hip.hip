@@ -1967,6 +1967,119 @@ int erf_cross_entropy_backward(const float *logits, const long long *target, con
     return 0;
 }
 
+// ================================================================================ masked regression losses
+static int ml_check(const char *what, int kind, const float *a, const float *b, const float *c, const float *target,
+                    int N, int K, int H, int W, long long &P, long long &blocks)
+{
+    if (kind < ML_L1 || kind > ML_LLCP) return fail("%s: unknown kind %d", what, kind);
+    if (N < 0 || H < 0 || W < 0) return fail("%s: negative extent", what);
+    const bool cls = kind == ML_L1CP || kind == ML_LLCP;
+    if (cls ? (K < 1 || K > ML_MAX_K) : K != 1)
+        return fail("%s: kind %d takes %s (got %d)", what, kind, cls ? "1..256 classes" : "one value per pixel", K);
+    P = (long long)N * H * W;
+    if (P == 0) return fail("%s: empty input", what);
+    if ((long long)H * W >= (1LL << 31)) return fail("%s: image too large", what);
+    blocks = (P + ML_BLOCK * ML_PPT - 1) / (ML_BLOCK * ML_PPT);
+    if (blocks >= (1LL << 31)) return fail("%s: too many pixels", what);
+    if (!a || !target || (kind != ML_L1 && !b) || (kind == ML_LLCP && !c)) return fail("%s: null pointer", what);
+    return 0;
+}
+
+int erf_masked_loss_forward(int kind, const float *a, const float *b, const float *c, const float *target,
+                            float eps, float *stats, int N, int K, int H, int W, void *ws, size_t ws_bytes,
+                            void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    long long P, blocks;
+    if (ml_check("masked loss", kind, a, b, c, target, N, K, H, W, P, blocks)) return 1;
+    if (!stats) return fail("masked loss: null pointer");
+    MlDesc d;
+    memset(&d, 0, sizeof(d));
+    d.a = a; d.b = b; d.c = c; d.target = target; d.P = P; d.HW = H * W; d.K = K; d.eps = eps;
+    d.partial = ar.floats((size_t)blocks * 2);
+    if (!d.partial) return fail("masked loss: workspace too small");
+    switch (kind) {
+    case ML_L1: ml_fwd_kernel<ML_L1><<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d); break;
+    case ML_LL: ml_fwd_kernel<ML_LL><<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d); break;
+    case ML_L1CP: ml_fwd_kernel<ML_L1CP><<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d); break;
+    default: ml_fwd_kernel<ML_LLCP><<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d); break;
+    }
+    CHECK_LAUNCH("ml_fwd_kernel");
+    ce_reduce_kernel<<<1, 256, 0, st>>>(d.partial, (int)blocks, stats);
+    CHECK_LAUNCH("ce_reduce_kernel");
+    return 0;
+}
+
+int erf_masked_loss_backward(int kind, const float *a, const float *b, const float *c, const float *target,
+                             float eps, const float *stats, const float *gy, float *da, float *db, float *dc,
+                             int N, int K, int H, int W, void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    long long P, blocks;
+    if (ml_check("masked loss backward", kind, a, b, c, target, N, K, H, W, P, blocks)) return 1;
+    if (!stats || !gy || !da || (kind == ML_LL && !db)) return fail("masked loss backward: null pointer");
+    MlDesc d;
+    memset(&d, 0, sizeof(d));
+    d.a = a; d.b = b; d.c = c; d.target = target; d.P = P; d.HW = H * W; d.K = K; d.eps = eps;
+    d.stats = stats; d.gy = gy; d.da = da; d.db = db;
+    const bool cls = kind == ML_L1CP || kind == ML_LLCP;
+    if (cls) {
+        d.partial = ar.floats((size_t)blocks * 2 * K);
+        if (!d.partial) return fail("masked loss backward: workspace too small");
+    }
+    switch (kind) {
+    case ML_L1: ml_bwd_kernel<ML_L1><<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d); break;
+    case ML_LL: ml_bwd_kernel<ML_LL><<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d); break;
+    case ML_L1CP: ml_bwd_kernel<ML_L1CP><<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d); break;
+    default: ml_bwd_kernel<ML_LLCP><<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d); break;
+    }
+    CHECK_LAUNCH("ml_bwd_kernel");
+    if (cls && (db || dc)) {
+        ml_colsum_kernel<<<(unsigned)K, 256, 0, st>>>(d.partial, (int)blocks, K, db, kind == ML_LLCP ? dc : nullptr);
+        CHECK_LAUNCH("ml_colsum_kernel");
+    }
+    return 0;
+}
+
+int erf_mse_mean_forward(const float *a, const float *b, long long n, float *stats, void *ws, size_t ws_bytes,
+                         void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (n <= 0) return fail("mse: empty input");
+    if (!a || !b || !stats) return fail("mse: null pointer");
+    const long long blocks = (n + ML_BLOCK * ML_PPT - 1) / (ML_BLOCK * ML_PPT);
+    if (blocks >= (1LL << 31)) return fail("mse: too many elements");
+    MseDesc d;
+    memset(&d, 0, sizeof(d));
+    d.a = a; d.b = b; d.n = n;
+    d.partial = ar.floats((size_t)blocks * 2);
+    if (!d.partial) return fail("mse: workspace too small");
+    mse_fwd_kernel<<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d);
+    CHECK_LAUNCH("mse_fwd_kernel");
+    ce_reduce_kernel<<<1, 256, 0, st>>>(d.partial, (int)blocks, stats);
+    CHECK_LAUNCH("ce_reduce_kernel");
+    return 0;
+}
+
+int erf_mse_mean_backward(const float *a, const float *b, const float *gy, float *da, long long n, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 0) return fail("mse: empty input");
+    if (!a || !b || !gy || !da) return fail("mse: null pointer");
+    const long long blocks = (n + ML_BLOCK * ML_PPT - 1) / (ML_BLOCK * ML_PPT);
+    if (blocks >= (1LL << 31)) return fail("mse: too many elements");
+    MseDesc d;
+    memset(&d, 0, sizeof(d));
+    d.a = a; d.b = b; d.gy = gy; d.da = da; d.n = n;
+    d.scale = (float)(1.0 / (double)n);
+    mse_bwd_kernel<<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d);
+    CHECK_LAUNCH("mse_bwd_kernel");
+    return 0;
+}
+
 // ================================================================================ iouEval counts
 int erf_iou_add_batch(const long long *pred, const long long *target, long long n_pixels, int n_classes,
                       int ignore_index, long long *counts, void *ws, size_t ws_bytes, void *stream)

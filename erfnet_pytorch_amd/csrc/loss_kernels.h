@@ -5,6 +5,8 @@
 // in backward, and the gradient is written once — torch's log_softmax + nll_loss pair moves the
 // N x K x H x W tensor six times.  A thread owns one pixel; consecutive threads take consecutive
 // pixels, so every class plane is read with fully coalesced 4-byte loads.
+// A label outside [0, K) that is not ignore_index counts as unlabelled (no loss, zero gradient, not in
+// the mean's denominator); torch's kernel stops the process with a device-side assert on such a label.
 #pragma once
 #include "common.h"
 
@@ -130,5 +132,263 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_bwd_kernel(const CeBwdDesc d)
     for (int k = 0; k < d.K; ++k) {
         const float pk = __expf(x[(long long)k * d.HW] - lse);
         g[(long long)k * d.HW] = valid ? (pk - (k == t ? 1.0f : 0.0f)) * scale : 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Masked regression losses of train/evaluation_functions.py: the mean, over the pixels whose target
+// is not -1, of a per-pixel value v(p):
+//   ML_L1     L1LossMasked (:89-97)                        v = |o - t|
+//   ML_LL     LogLikelihoodLossMasked (:71-87)             v = log(2 pi s) + (c - t)^2 / s,  s = var + eps
+//   ML_L1CP   L1LossClassProbMasked (:32-47)               v = sum_k prob_k |cost_k - t|
+//   ML_LLCP   LogLikelihoodLossClassProbMasked (:49-69)    v = sum_k prob_k (log(2 pi s_k) + (cost_k - t)^2 / s_k)
+// a: o / c / prob ([N][K][HW], K = 1 for the first two); b: var [N][HW] (ML_LL) or cost [K];
+// c: var [K] (ML_LLCP).  torch builds these from five to nine elementwise kernels and a masked_select
+// (a prefix sum and a compaction); here the inputs are read once per direction.
+// A thread owns ML_PPT pixels ML_BLOCK apart, so every plane is read with coalesced 4-byte loads.
+#define ML_BLOCK 256
+#define ML_PPT 4
+#define ML_MAX_K 256
+enum { ML_L1 = 0, ML_LL = 1, ML_L1CP = 2, ML_LLCP = 3 };
+
+struct MlDesc {
+    const float *a, *b, *c, *target;
+    const float *stats, *gy;            // backward: stats[1] = number of labelled pixels, gy = d loss
+    float *da, *db;                     // backward: gradients with the shape of a, and of b for ML_LL
+    float *partial;                     // forward [blocks][2]; backward (class kinds) [blocks][2K]
+    long long P;                        // N * HW
+    int HW, K;
+    float eps;
+};
+
+#define ML_TWO_PI 6.283185307179586f
+
+// per-class constants of the class-probability kinds: cost, log(2 pi s), 1 / s
+template <int KIND>
+__device__ __forceinline__ void ml_class_consts(const MlDesc &d, float *cost, float *lv, float *iv)
+{
+    if (KIND == ML_L1CP || KIND == ML_LLCP) {
+        for (int k = threadIdx.x; k < d.K; k += ML_BLOCK) {
+            cost[k] = d.b[k];
+            if (KIND == ML_LLCP) {
+                const float s = d.c[k] + d.eps;
+                lv[k] = logf(ML_TWO_PI * s);
+                iv[k] = 1.0f / s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(ML_BLOCK) void ml_fwd_kernel(const MlDesc d)
+{
+    __shared__ float cost[ML_MAX_K], lv[ML_MAX_K], iv[ML_MAX_K];
+    __shared__ float red[2][ML_BLOCK / 64];
+    ml_class_consts<KIND>(d, cost, lv, iv);
+    float loss = 0.0f, cnt = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ML_PPT; ++i) {
+        const long long p = ((long long)blockIdx.x * ML_PPT + i) * ML_BLOCK + threadIdx.x;
+        if (p >= d.P) break;
+        const float t = d.target[p];
+        float v;
+        if (KIND == ML_L1) {
+            v = fabsf(d.a[p] - t);
+        } else if (KIND == ML_LL) {
+            const float s = d.b[p] + d.eps, e = d.a[p] - t;
+            v = logf(ML_TWO_PI * s) + e * e / s;
+        } else {
+            const long long n = p / d.HW;
+            const float *pr = d.a + n * (long long)d.K * d.HW + (p - n * d.HW);
+            v = 0.0f;
+            for (int k = 0; k < d.K; ++k) {
+                const float e = cost[k] - t;
+                const float wk = KIND == ML_L1CP ? fabsf(e) : lv[k] + e * e * iv[k];
+                v += wk * pr[(long long)k * d.HW];
+            }
+        }
+        if (t != -1.0f) {
+            loss += v;
+            cnt += 1.0f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        loss += __shfl_xor(loss, o);
+        cnt += __shfl_xor(cnt, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = loss;
+        red[1][threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float x = 0.0f, y = 0.0f;
+#pragma unroll
+        for (int w = 0; w < ML_BLOCK / 64; ++w) { x += red[0][w]; y += red[1][w]; }
+        d.partial[2 * (long long)blockIdx.x + 0] = x;
+        d.partial[2 * (long long)blockIdx.x + 1] = y;
+    }
+}
+
+// Gradients.  With g = gy / (number of labelled pixels), on labelled pixels (zero elsewhere):
+//   ML_L1    do = sign(o - t) g
+//   ML_LL    dc = 2 (c - t) / s g,               dvar = (1 / s - (c - t)^2 / s^2) g
+//   ML_L1CP  dprob_k = |cost_k - t| g,           dcost_k = sum_p prob_k sign(cost_k - t) g
+//   ML_LLCP  dprob_k = (log(2 pi s_k) + e^2/s_k) g,   dcost_k = sum_p prob_k 2 e / s_k g,
+//            dvar_k = sum_p prob_k (1 / s_k - e^2 / s_k^2) g          (e = cost_k - t)
+// The per-class sums leave the block as partial[block][k] (cost) and partial[block][K + k] (var) and
+// are added in a fixed order by ml_colsum_kernel.
+template <int KIND>
+__global__ __launch_bounds__(ML_BLOCK) void ml_bwd_kernel(const MlDesc d)
+{
+    __shared__ float cost[ML_MAX_K], lv[ML_MAX_K], iv[ML_MAX_K];
+    __shared__ float red[2][ML_BLOCK / 64];
+    ml_class_consts<KIND>(d, cost, lv, iv);
+    const float g = d.gy[0] / d.stats[1];
+    float t[ML_PPT];
+    long long off[ML_PPT];      // offset of the pixel inside plane 0 of its image; -1 beyond the end
+#pragma unroll
+    for (int i = 0; i < ML_PPT; ++i) {
+        const long long p = ((long long)blockIdx.x * ML_PPT + i) * ML_BLOCK + threadIdx.x;
+        if (p < d.P) {
+            t[i] = d.target[p];
+            const long long n = p / d.HW;
+            off[i] = (KIND == ML_L1 || KIND == ML_LL) ? p : n * (long long)d.K * d.HW + (p - n * d.HW);
+        } else {
+            t[i] = -1.0f;
+            off[i] = -1;
+        }
+    }
+    if (KIND == ML_L1 || KIND == ML_LL) {
+#pragma unroll
+        for (int i = 0; i < ML_PPT; ++i) {
+            if (off[i] < 0) continue;
+            const bool valid = t[i] != -1.0f;
+            const float e = d.a[off[i]] - t[i];
+            if (KIND == ML_L1) {
+                d.da[off[i]] = valid ? (e > 0.0f ? g : e < 0.0f ? -g : 0.0f) : 0.0f;
+            } else {
+                const float is = 1.0f / (d.b[off[i]] + d.eps);
+                d.da[off[i]] = valid ? 2.0f * e * is * g : 0.0f;
+                d.db[off[i]] = valid ? (is - e * e * is * is) * g : 0.0f;
+            }
+        }
+        return;
+    }
+    for (int k = 0; k < d.K; ++k) {
+        float sc = 0.0f, sv = 0.0f;
+#pragma unroll
+        for (int i = 0; i < ML_PPT; ++i) {
+            if (off[i] < 0) continue;
+            const bool valid = t[i] != -1.0f;
+            const long long o = off[i] + (long long)k * d.HW;
+            const float e = cost[k] - t[i];
+            const float pr = valid ? d.a[o] : 0.0f;
+            if (KIND == ML_L1CP) {
+                d.da[o] = valid ? fabsf(e) * g : 0.0f;
+                sc += pr * (e > 0.0f ? g : e < 0.0f ? -g : 0.0f);
+            } else {
+                d.da[o] = valid ? (lv[k] + e * e * iv[k]) * g : 0.0f;
+                sc += pr * 2.0f * e * iv[k] * g;
+                sv += pr * (iv[k] - e * e * iv[k] * iv[k]) * g;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sc += __shfl_xor(sc, o);
+            sv += __shfl_xor(sv, o);
+        }
+        __syncthreads();        // the previous class's sums have been read
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = sc;
+            red[1][threadIdx.x >> 6] = sv;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float x = 0.0f, y = 0.0f;
+#pragma unroll
+            for (int w = 0; w < ML_BLOCK / 64; ++w) { x += red[0][w]; y += red[1][w]; }
+            d.partial[(long long)blockIdx.x * 2 * d.K + k] = x;
+            d.partial[(long long)blockIdx.x * 2 * d.K + d.K + k] = y;
+        }
+    }
+}
+
+// out0[j] = sum over rows of partial[row][j], out1[j] = ... partial[row][J + j]   (rows of 2J floats);
+// one block per column pair, fixed order, double accumulators.
+__global__ __launch_bounds__(256) void ml_colsum_kernel(const float *partial, int rows, int J, float *out0, float *out1)
+{
+    __shared__ double red[2][256];
+    const int j = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < rows; i += 256) {
+        a += partial[(long long)i * 2 * J + j];
+        b += partial[(long long)i * 2 * J + J + j];
+    }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + o];
+            red[1][threadIdx.x] += red[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (out0) out0[j] = (float)red[0][0];
+        if (out1) out1[j] = (float)red[1][0];
+    }
+}
+
+// Mean squared difference of two tensors of n elements (the elementwise part of MSELossWeighted,
+// train/evaluation_functions.py:122-131; the caller multiplies by scale_factor * weight):
+// partial[block] = {sum (a - b)^2, elements}; the gradient is 2 (a - b) gy / n.
+struct MseDesc {
+    const float *a, *b, *gy;
+    float *da, *partial;
+    long long n;
+    float scale;
+};
+
+__global__ __launch_bounds__(ML_BLOCK) void mse_fwd_kernel(const MseDesc d)
+{
+    __shared__ float red[ML_BLOCK / 64];
+    float s = 0.0f, c = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ML_PPT; ++i) {
+        const long long p = ((long long)blockIdx.x * ML_PPT + i) * ML_BLOCK + threadIdx.x;
+        if (p < d.n) {
+            const float e = d.a[p] - d.b[p];
+            s += e * e;
+            c += 1.0f;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        c += __shfl_xor(c, o);
+    }
+    __shared__ float redc[ML_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; redc[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float x = 0.0f, y = 0.0f;
+#pragma unroll
+        for (int w = 0; w < ML_BLOCK / 64; ++w) { x += red[w]; y += redc[w]; }
+        d.partial[2 * (long long)blockIdx.x] = x;
+        d.partial[2 * (long long)blockIdx.x + 1] = y;
+    }
+}
+
+__global__ __launch_bounds__(ML_BLOCK) void mse_bwd_kernel(const MseDesc d)
+{
+    const float g = 2.0f * d.gy[0] * d.scale;      // scale = 1 / n
+#pragma unroll
+    for (int i = 0; i < ML_PPT; ++i) {
+        const long long p = ((long long)blockIdx.x * ML_PPT + i) * ML_BLOCK + threadIdx.x;
+        if (p < d.n) d.da[p] = (d.a[p] - d.b[p]) * g;
     }
 }

@@ -1,4 +1,4 @@
-"""Drop-in for the classification loss and accuracy metrics of ``train/evaluation_functions.py``.
+"""Drop-in for the losses and accuracy metrics of ``train/evaluation_functions.py``.
 
 ``CrossEntropyLoss2d`` (train/evaluation_functions.py:6-14) is
 ``torch.nn.CrossEntropyLoss(ignore_index=-1)`` behind a module; ``train/main.py:186-188`` builds
@@ -23,6 +23,101 @@ class CrossEntropyLoss2d(torch.nn.Module):
         if outputs.is_cuda and outputs.dim() == 4 and outputs.dtype == torch.float32:
             return F_hip.cross_entropy(outputs, targets, -1)
         return self.loss(outputs, targets)
+
+
+def _gpu_f32(*ts):
+    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+def _labelled_mean(values, targets):
+    """CPU path of the masked losses: mean of `values` where the target carries a label."""
+    return values[targets != -1.0].mean()
+
+
+class L1LossMasked(torch.nn.Module):
+    """mean |output - target| over the pixels whose target is not -1
+    (train/evaluation_functions.py:89-97); outputs [N,1,H,W], targets [N,H,W]."""
+
+    def forward(self, outputs, targets):
+        if _gpu_f32(outputs, targets) and outputs.dim() == 4 and outputs.shape[1] == 1:
+            return F_hip.masked_loss(F_hip.ML_L1, outputs, None, None, targets)
+        return _labelled_mean((outputs.squeeze(1) - targets).abs(), targets)
+
+
+class LogLikelihoodLossMasked(torch.nn.Module):
+    """mean of log(2 pi s) + (cost - target)^2 / s, s = var + opt_eps, over the labelled pixels — the
+    Gaussian negative log-likelihood without its factor 1/2 (train/evaluation_functions.py:71-87)."""
+
+    def __init__(self, opt_eps=0.0):
+        super().__init__()
+        self.opt_eps = opt_eps
+
+    def forward(self, output_cost, output_var, targets):
+        if _gpu_f32(output_cost, output_var, targets) and output_cost.shape == output_var.shape == targets.shape:
+            n = targets.shape[0] if targets.dim() > 1 else 1
+            a = output_cost.reshape(n, 1, 1, -1)
+            return F_hip.masked_loss(F_hip.ML_LL, a, output_var.reshape(n, 1, -1), None, targets.reshape(n, 1, -1),
+                                     self.opt_eps)
+        s = output_var + self.opt_eps
+        return _labelled_mean(torch.log(2 * np.pi * s) + (output_cost - targets) ** 2 / s, targets)
+
+
+def _class_operands(prob, *per_class):
+    k = prob.shape[1]
+    return all(t.numel() == k for t in per_class)
+
+
+class L1LossClassProbMasked(torch.nn.Module):
+    """mean over the labelled pixels of sum_k prob_k |cost_k - target|
+    (train/evaluation_functions.py:32-47); prob [N,K,H,W], cost [1,K,1,1], targets [N,H,W]."""
+
+    def forward(self, output_prob, output_cost, targets):
+        if _gpu_f32(output_prob, output_cost, targets) and output_prob.dim() == 4 \
+                and _class_operands(output_prob, output_cost) and output_prob.shape[1] <= 256:
+            return F_hip.masked_loss(F_hip.ML_L1CP, output_prob, output_cost.reshape(-1), None, targets)
+        t = targets.unsqueeze(1)
+        per_pixel = ((output_cost - t).abs() * output_prob).sum(dim=1, keepdim=True)
+        return _labelled_mean(per_pixel, t)
+
+
+class LogLikelihoodLossClassProbMasked(torch.nn.Module):
+    """mean over the labelled pixels of sum_k prob_k (log(2 pi s_k) + (cost_k - target)^2 / s_k),
+    s_k = var_k + opt_eps (train/evaluation_functions.py:49-69)."""
+
+    def __init__(self, opt_eps=0.0):
+        super().__init__()
+        self.opt_eps = opt_eps
+
+    def forward(self, output_prob, output_cost, output_var, targets):
+        if _gpu_f32(output_prob, output_cost, output_var, targets) and output_prob.dim() == 4 \
+                and _class_operands(output_prob, output_cost, output_var) and output_prob.shape[1] <= 256:
+            return F_hip.masked_loss(F_hip.ML_LLCP, output_prob, output_cost.reshape(-1), output_var.reshape(-1),
+                                     targets, self.opt_eps)
+        t = targets.unsqueeze(1)
+        s = output_var + self.opt_eps
+        per_class = torch.log(2 * np.pi * s) + (output_cost - t) ** 2 / s
+        return _labelled_mean((per_class * output_prob).sum(dim=1, keepdim=True), t)
+
+
+class L1Loss(torch.nn.Module):
+    """nn.L1Loss with mean reduction behind a module (train/evaluation_functions.py:112-120)."""
+
+    def forward(self, outputs, targets):
+        return torch.nn.functional.l1_loss(outputs, targets)
+
+
+class MSELossWeighted(torch.nn.Module):
+    """mean((outputs - targets)^2 * scale_factor * weight): the mean-teacher consistency loss
+    (train/evaluation_functions.py:122-131; train/main.py:191,341,353)."""
+
+    def __init__(self, scale_factor):
+        super().__init__()
+        self.scale_factor = scale_factor
+
+    def forward(self, outputs, targets, weight):
+        if _gpu_f32(outputs, targets) and outputs.shape == targets.shape and outputs.numel() > 0:
+            return F_hip.mse_mean(outputs, targets) * (self.scale_factor * weight)
+        return ((outputs - targets) ** 2 * self.scale_factor * weight).mean()
 
 
 def _accuracy_counts(prob, targets):
@@ -76,15 +171,12 @@ class MeanAccuracy():
             class_acc = counts[0] / counts[1]
             present = counts[1] > 0
             return class_acc[present].sum() / present.sum(), class_acc.numpy()
-        max_class = prob.argmax(dim=1, keepdim=True).squeeze()
-        correct_pred = max_class.masked_select(max_class == targets)
-        mean_acc, num_classes, class_acc = 0, 0, []
-        for cur_class in range(0, self.n_classes):
-            n_correct = (correct_pred == cur_class).sum().float()
-            n_total = (targets == cur_class).sum().float()
-            cur_acc = n_correct / n_total
-            class_acc.append(float(cur_acc))
-            if n_total > 0:
-                num_classes += 1
-                mean_acc += cur_acc
-        return mean_acc / num_classes, np.array(class_acc)
+        # CPU tensors: two histograms over the label classes instead of a loop of masked counts
+        pred = prob.argmax(dim=1).reshape(-1)
+        label = targets.reshape(-1).to(torch.int64)
+        keep = (label >= 0) & (label < self.n_classes)
+        total = torch.bincount(label[keep], minlength=self.n_classes).float()
+        hit = torch.bincount(label[keep & (pred == label)], minlength=self.n_classes).float()
+        class_acc = hit / total
+        present = total > 0
+        return class_acc[present].sum() / present.sum(), class_acc.numpy()

@@ -812,3 +812,97 @@ def cross_entropy(logits, target, ignore_index=-1):
     """nn.CrossEntropyLoss(ignore_index)(logits, target) for [N,K,H,W] logits and [N,H,W] int64
     targets (the reference's CrossEntropyLoss2d, train/evaluation_functions.py:6-14) on the GPU."""
     return _CrossEntropy.apply(logits, target, ignore_index)
+
+
+# ------------------------------------------------------------------------------ masked regression losses
+ML_L1, ML_LL, ML_L1CP, ML_LLCP = 0, 1, 2, 3
+
+
+def _f32c(t, what):
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: fp32 tensors only, got {t.dtype}")
+    return t.contiguous()
+
+
+class _MaskedLoss(torch.autograd.Function):
+    """a: [N,K,H,W]; b: [N,H,W] (ML_LL), [K] values (class kinds) or None; c: [K] values or None;
+    target: [N,H,W] float, -1 = no label."""
+
+    @staticmethod
+    def forward(ctx, kind, eps, a, b, c, target):
+        lib = _lib.lib()
+        n, k, h, wd = a.shape
+        a = _f32c(a, "masked loss")
+        b = None if b is None else _f32c(b, "masked loss")
+        c = None if c is None else _f32c(c, "masked loss")
+        tg = _f32c(target, "masked loss")
+        if tg.numel() != n * h * wd:
+            raise ValueError(f"masked loss: target shape {tuple(target.shape)} does not match {tuple(a.shape)}")
+        want = {ML_L1: 0, ML_LL: n * h * wd, ML_L1CP: k, ML_LLCP: k}[kind]
+        if (0 if b is None else b.numel()) != want or (0 if c is None else c.numel()) != (k if kind == ML_LLCP else 0):
+            raise ValueError("masked loss: operand sizes do not match the kind")
+        stats = torch.empty(2, dtype=torch.float32, device=a.device)
+        ws = _workspace(a, n * h * wd, k)
+        with _dev_ctx(a):
+            _lib.check(lib.erf_masked_loss_forward(kind, _p(a), _p(b), _p(c), _p(tg), float(eps), _p(stats), n, k,
+                                                   h, wd, _p(ws), ws.numel(), _stream(a)))
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(a, b, c, tg, stats)
+            ctx.cfg = (kind, float(eps))
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        a, b, c, tg, stats = ctx.saved_tensors
+        kind, eps = ctx.cfg
+        n, k, h, wd = a.shape
+        gy = gy.to(torch.float32).reshape(1).contiguous()
+        da = torch.empty_like(a)
+        db = None if b is None else torch.empty_like(b)
+        dc = None if c is None else torch.empty_like(c)
+        ws = _workspace(a, n * h * wd, k)
+        with _dev_ctx(a):
+            _lib.check(lib.erf_masked_loss_backward(kind, _p(a), _p(b), _p(c), _p(tg), eps, _p(stats), _p(gy),
+                                                    _p(da), _p(db), _p(dc), n, k, h, wd, _p(ws), ws.numel(),
+                                                    _stream(a)))
+        return None, None, da, db, dc, None
+
+
+def masked_loss(kind, a, b, c, target, eps=0.0):
+    """Mean over the labelled pixels (target != -1) of the per-pixel value of one of the reference's
+    masked regression losses (train/evaluation_functions.py:32-97), forward and backward as one HIP
+    kernel each.  a [N,K,H,W]; b, c: see _MaskedLoss."""
+    return _MaskedLoss.apply(kind, eps, a, b, c, target)
+
+
+class _MseMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.lib()
+        if a.shape != b.shape:
+            raise ValueError(f"mse: shapes {tuple(a.shape)} and {tuple(b.shape)} differ")
+        a, b = _f32c(a, "mse"), _f32c(b, "mse")
+        stats = torch.empty(2, dtype=torch.float32, device=a.device)
+        ws = _workspace(a, a.numel(), 1)
+        with _dev_ctx(a):
+            _lib.check(lib.erf_mse_mean_forward(_p(a), _p(b), a.numel(), _p(stats), _p(ws), ws.numel(), _stream(a)))
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(a, b)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        a, b = ctx.saved_tensors
+        gy = gy.to(torch.float32).reshape(1).contiguous()
+        da = torch.empty_like(a)
+        with _dev_ctx(a):
+            _lib.check(lib.erf_mse_mean_backward(_p(a), _p(b), _p(gy), _p(da), a.numel(), _stream(a)))
+        # d/db = -d/da; the consistency loss's second operand is the detached teacher output
+        return (da if ctx.needs_input_grad[0] else None), (-da if ctx.needs_input_grad[1] else None)
+
+
+def mse_mean(a, b):
+    """mean((a - b)^2) (the elementwise part of MSELossWeighted, train/evaluation_functions.py:122-131)."""
+    return _MseMean.apply(a, b)

@@ -29,12 +29,14 @@ class GraphedForward:
         side = torch.cuda.Stream(device=example.device)
         side.wait_stream(torch.cuda.current_stream(example.device))
         with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):            # allocates the per-stream workspace outside the capture
+            # the workspace cache is keyed by stream: warm up on the stream the capture runs on,
+            # so the capture finds its workspace and allocates nothing
+            for _ in range(warmup):
                 model(self.static_in)
         torch.cuda.current_stream(example.device).wait_stream(side)
         torch.cuda.synchronize(example.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
             self.static_out = model(self.static_in)
 
     def __call__(self, x):

@@ -194,7 +194,8 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
  * logits NCHW-contiguous [N,K,H,W] fp32 (what erf_outconv_forward writes); target [N,H,W] int64 with
  * values in [0,K) or ignore_index.  stats[2] (device) receives {mean of -log softmax[target] over
  * the labelled pixels, number of labelled pixels}; lse [N,H,W] receives the per-pixel log-sum-exp
- * that backward reuses.  No pixel labelled -> stats[0] is NaN, as in torch. */
+ * that backward reuses.  No pixel labelled -> stats[0] is NaN, as in torch.  Any other label outside
+ * [0,K) is treated like ignore_index (torch aborts with a device-side assert on such a label). */
 int erf_cross_entropy_forward(const float *logits, const long long *target, float *stats, float *lse,
                               int N, int K, int H, int W, long long ignore_index, void *ws,
                               size_t ws_bytes, void *stream);
@@ -214,6 +215,35 @@ int erf_cross_entropy_forward_static(const float *logits, const long long *targe
 int erf_cross_entropy_backward(const float *logits, const long long *target, const float *lse,
                                const float *stats, const float *gy, float *dlogits, int N, int K, int H,
                                int W, long long ignore_index, void *stream);
+
+/* ---- masked regression losses (train/evaluation_functions.py:32-97; train/main.py:173-184) ------
+ * The mean, over the pixels whose float target is not -1, of a per-pixel value:
+ *   kind 0  L1LossMasked (:89-97)                      |a - t|                         K = 1
+ *   kind 1  LogLikelihoodLossMasked (:71-87)           log(2 pi s) + (a - t)^2 / s,  s = b + eps, K = 1
+ *   kind 2  L1LossClassProbMasked (:32-47)             sum_k a_k |b_k - t|
+ *   kind 3  LogLikelihoodLossClassProbMasked (:49-69)  sum_k a_k (log(2 pi s_k) + (b_k - t)^2 / s_k),
+ *                                                      s_k = c_k + eps (the reference's class adds no
+ *                                                      eps of its own: pass its opt_eps)
+ * a: [N][K][H][W] (network output, cost, or class probabilities); b: variance [N][H][W] (kind 1) or
+ * the per-class cost [K] (kinds 2, 3); c: the per-class variance [K] (kind 3); target: [N][H][W].
+ * stats: device float[2] = {mean, number of labelled pixels}; mean is NaN when nothing is labelled,
+ * as the reference's mean of an empty selection.  Backward: da like a; db like b (kinds 1-3, may be
+ * NULL for 2, 3); dc like c (kind 3, may be NULL); gy is the device scalar d(loss).
+ * workspace: 8 bytes per 1024 pixels forward, 8 K bytes per 1024 pixels backward (kinds 2, 3). */
+int erf_masked_loss_forward(int kind, const float *a, const float *b, const float *c, const float *target,
+                            float eps, float *stats, int N, int K, int H, int W, void *ws, size_t ws_bytes,
+                            void *stream);
+int erf_masked_loss_backward(int kind, const float *a, const float *b, const float *c, const float *target,
+                             float eps, const float *stats, const float *gy, float *da, float *db, float *dc,
+                             int N, int K, int H, int W, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- MSELossWeighted (train/evaluation_functions.py:122-131; the mean-teacher consistency loss,
+ * train/main.py:191,341,353) ------------------------------------------------------------------------
+ * stats[0] = mean((a - b)^2) over n elements, stats[1] = n; the caller multiplies by
+ * scale_factor * weight.  Backward: da = 2 (a - b) gy[0] / n. */
+int erf_mse_mean_forward(const float *a, const float *b, long long n, float *stats, void *ws, size_t ws_bytes,
+                         void *stream);
+int erf_mse_mean_backward(const float *a, const float *b, const float *gy, float *da, long long n, void *stream);
 
 /* ---- iouEval.addBatch for label maps (train/iouEval.py:21-70, eval/iouEval.py) ------------------
  * pred, target: int64 class indices, n_pixels each (the [N,1,H,W] tensors the scripts pass:

@@ -372,3 +372,48 @@ def erfnet_train_pass(x, labels, state, prefix_style="train"):
             g, dw, db, _, _ = upsampler_bwd(xin, w, y, None, g)
             grads[names[i]], grads[names[i + 1]] = dw, db
     return loss, grads
+
+
+# ---------------------------------------------------------------------------- masked regression losses
+def masked_loss(kind, a, b, c, target, eps=0.0):
+    """float64 numpy restatement of the reference's masked regression losses and their gradients
+    (train/evaluation_functions.py): kind "l1" :89-97, "ll" :71-87, "l1cp" :32-47, "llcp" :49-69.
+    a: [N,K,H,W] (K = 1 for l1 / ll); b: [N,H,W] variance (ll) or [K] cost; c: [K] variance (llcp);
+    target: [N,H,W], -1 = no label.  Returns (loss, da, db, dc)."""
+    a = np.asarray(a, np.float64)
+    t = np.asarray(target, np.float64)[:, None]                     # [N,1,H,W]
+    valid = t != -1.0
+    cnt = valid.sum()
+    g = valid / cnt if cnt else valid * np.nan
+    db = dc = None
+    if kind == "l1":
+        v = np.abs(a - t)
+        da = np.sign(a - t) * g
+    elif kind == "ll":
+        s = np.asarray(b, np.float64)[:, None] + eps
+        e = a - t
+        v = np.log(2 * np.pi * s) + e * e / s
+        da = 2 * e / s * g
+        db = ((1 / s - e * e / (s * s)) * g)[:, 0]
+    else:
+        cost = np.asarray(b, np.float64).reshape(1, -1, 1, 1)
+        e = cost - t
+        if kind == "l1cp":
+            wk = np.abs(e)
+            db = (a * np.sign(e) * g).sum(axis=(0, 2, 3))
+        else:
+            s = np.asarray(c, np.float64).reshape(1, -1, 1, 1) + eps
+            wk = np.log(2 * np.pi * s) + e * e / s
+            db = (a * 2 * e / s * g).sum(axis=(0, 2, 3))
+            dc = (a * (1 / s - e * e / (s * s)) * g).sum(axis=(0, 2, 3))
+        v = (wk * a).sum(axis=1, keepdims=True)
+        da = wk * g
+    loss = v[valid].mean() if cnt else np.nan
+    return loss, da, db, dc
+
+
+def mse_weighted(a, b, scale_factor, weight):
+    """MSELossWeighted (train/evaluation_functions.py:122-131): value and gradient w.r.t. a."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    e = a - b
+    return (e * e * scale_factor * weight).mean(), 2 * e * scale_factor * weight / e.size

@@ -401,33 +401,47 @@ def test_cross_entropy_nothing_labelled_is_nan():
     assert torch.isnan(torch.nn.functional.cross_entropy(x, lab, ignore_index=-1))
 
 
-def test_relu_mask_hand_over_leaves_gradients_unchanged(monkeypatch):
+@pytest.mark.parametrize("key", ["net_classification_20", "net_classification_ladder_20", "net_regression_ladder_0",
+                                 "net_regression_ladder_small_0"])
+def test_relu_mask_hand_over_leaves_gradients_unchanged(key, monkeypatch):
     """Neighbouring blocks hand the ReLU mask of the gradient over (consumer masks its dx, producer
     skips its masking pass).  Every parameter gradient and the input gradient must be bit-identical
-    to the run in which no block knows its neighbour."""
+    to the run in which no block knows its neighbour — also in the ladder nets, whose encoder
+    outputs have two consumers (the next block and a LadderBlock), and also for a second backward
+    through a retained graph, when the tokens of the first pass have been used up."""
     from erfnet_pytorch_amd import functional as hipf
     x_np = gu.det_uniform("handover.x", (2, 3, 64, 128), 0.0, 1.0)
-    lab = t(gu.det_labels("handover.lab", (2, 64, 128), -1, 20))
+    g_np = None
     res = []
     for hand_over in (True, False):
         if not hand_over:
             monkeypatch.setattr(hipf, "_input_token", lambda x: None)
-        net = gu.fill_state_dict(make_model("net_classification_20"), tag="trainstep").to(DEV).train()
+        net = gu.fill_state_dict(make_model(key), tag="handover." + key).to(DEV).train()
         for m in net.modules():           # dropout off: both runs must see the same network
             if isinstance(m, torch.nn.Dropout2d):
                 m.p = 0.0
         x = t(x_np).contiguous(memory_format=torch.channels_last).requires_grad_(True)
         n0 = launches()
-        out, _ = net(x)
-        torch.nn.functional.cross_entropy(out, lab, ignore_index=-1).backward()
-        res.append(({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None},
-                    x.grad.clone(), launches() - n0))
-    (ga, xa, la), (gb, xb, lb) = res
+        out = first(net(x))
+        if g_np is None:
+            g_np = gu.det_normal("handover.g", tuple(out.shape))
+        g = t(g_np)
+        out.backward(g, retain_graph=True)
+        one = ({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, x.grad.clone(),
+               launches() - n0)
+        net.zero_grad(set_to_none=True)
+        x.grad = None
+        out.backward(g)
+        two = ({k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}, x.grad.clone())
+        res.append((one, two))
+    ((ga, xa, la), (ga2, xa2)), ((gb, xb, lb), (gb2, xb2)) = res
     assert la < lb                        # the masking passes really were skipped
-    assert ga.keys() == gb.keys()
+    assert ga.keys() == gb.keys() == ga2.keys() == gb2.keys()
     for k in ga:
         assert torch.equal(ga[k], gb[k]), k
-    assert torch.equal(xa, xb)
+        assert torch.equal(ga2[k], gb[k]), ("second backward", k)
+        assert torch.equal(gb2[k], gb[k]), ("second backward, no hand-over", k)
+    assert torch.equal(xa, xb) and torch.equal(xa2, xb) and torch.equal(xb2, xb)
 
 
 def test_graphed_forward_replays_the_eager_result():
