@@ -33,9 +33,19 @@ def chk_fwd(case, key, arr):
     gu.check(BLK, f"{case}/{key}", arr, FWD_ATOL, FWD_RTOL, what=f"{case}/{key}")
 
 
+# Gradients against the goldens: a ReLU whose pre-activation is within rounding of zero can open on
+# one side and not on the other, which changes the few gradient elements that pixel feeds; 0.5 % of
+# the elements may therefore miss the tolerance (by at most 2 % of the tensor's scale).  Two cases
+# need more room in the weight gradient of their FIRST convolution, which sums over every pixel of
+# three later ReLUs (24 and 65 of 4096 sampled elements on gfx950); the same blocks compare strictly
+# in test_nb1d_c_abi_against_oracle / test_nb1d_c_abi_batchnorm_against_oracle, where both sides
+# use the same masks.
+OUTLIER_FRAC = {"nb1d_128_d16_bn1": 0.01, "nb1d_64_d2_bn0_drop": 0.02}
+
+
 def chk_grad(case, key, arr):
     gu.check(BLK, f"{case}/{key}", arr, FWD_ATOL, FWD_RTOL, what=f"{case}/{key}", scale_rtol=3e-4,
-             outlier_frac=0.05, outlier_rtol=0.02)
+             outlier_frac=OUTLIER_FRAC.get(case, 0.005), outlier_rtol=0.02)
 
 
 def build_block(c):
@@ -198,6 +208,94 @@ def test_nb1d_c_abi_against_oracle(C_, dil, N, H, W):
         gu.check_arrays(gdw[i].cpu().numpy().reshape(ws[i].shape), dws_ref[i], 5e-4, 5e-4,
                         what=f"dw{i}", scale_rtol=2e-4)
         gu.check_arrays(gdb[i].cpu().numpy(), dbs_ref[i], 5e-4, 5e-4, what=f"db{i}", scale_rtol=2e-4)
+
+
+@pytest.mark.parametrize("C_,dil,N,H,W,mode,drop", [(64, 2, 2, 20, 24, 2, False), (128, 4, 2, 12, 20, 2, True),
+                                                    (16, 1, 3, 17, 33, 2, False), (64, 8, 1, 20, 24, 1, True)])
+def test_nb1d_c_abi_batchnorm_against_oracle(C_, dil, N, H, W, mode, drop):
+    """The BatchNorm variants of the block (train/erfnet_blocks.py:35-73) on raw pointers vs the
+    oracle: forward incl. batch statistics and running-statistics update, then the backward fed with
+    the oracle's saved activations AND saved mean / 1/std, so both sides differentiate the same
+    function at the same point and every gradient (dx, dW, db, dgamma, dbeta) compares strictly."""
+    from erfnet_pytorch_amd import _lib
+    from oracle import oracle as orc
+    lib = _lib.lib()
+    tag = f"abi_nb1d_bn_{C_}_{dil}_{mode}"
+    x = np.maximum(gu.det_normal(tag + ".x", (N, C_, H, W)), 0)
+    shapes = [(C_, C_, 3, 1), (C_, C_, 1, 3), (C_, C_, 3, 1), (C_, C_, 1, 3)]
+    names = ("conv3x1_1", "conv1x3_1", "conv3x1_2", "conv1x3_2")
+    ws = [gu.fill_value(f"{n}.weight", s, tag) for n, s in zip(names, shapes)]
+    bs = [gu.fill_value(f"{n}.bias", (C_,), tag) for n in names]
+    bn_np = [dict(gamma=gu.det_uniform(f"{tag}.bn{i}.g", (C_,), 0.5, 1.5), beta=0.1 * gu.det_normal(f"{tag}.bn{i}.b", (C_,)),
+                  running_mean=0.1 * gu.det_normal(f"{tag}.bn{i}.rm", (C_,)),
+                  running_var=gu.det_uniform(f"{tag}.bn{i}.rv", (C_,), 0.5, 1.5)) for i in (1, 2)]
+    obn = [orc.BN(mode, **b) for b in bn_np]
+    ds = None
+    if drop:
+        ds = ((gu.det_uniform(tag + ".keep", (N, C_), 0, 1) >= 0.3) / 0.7).astype(np.float32)
+    y_ref, sv = orc.nb1d_fwd(x, ws, bs, dil, obn[0], obn[1], ds, save=True)
+    gy = gu.det_normal(tag + ".gy", y_ref.shape)
+    dx_ref, dws_ref, dbs_ref, dgs_ref, dbts_ref = orc.nb1d_bwd(x, ws, dil, y_ref, sv, gy, obn[0], obn[1], ds)
+
+    keep = []           # device tensors referenced by raw pointers
+
+    def dev(a):
+        keep.append(t(np.asarray(a, np.float32)))
+        return keep[-1]
+
+    def bn_struct(b, save_mean=None, save_invstd=None):
+        f = {k: dev(v) for k, v in b.items()}
+        sm = dev(np.zeros(C_) if save_mean is None else save_mean)
+        si = dev(np.zeros(C_) if save_invstd is None else save_invstd)
+        st = _lib.BnStruct(mode, f["gamma"].data_ptr(), f["beta"].data_ptr(), f["running_mean"].data_ptr(),
+                           f["running_var"].data_ptr(), sm.data_ptr(), si.data_ptr(), 0.1, 1e-3)
+        return st, f, sm, si
+
+    arr = lambda ts: (C.c_void_p * len(ts))(*[None if x_ is None else x_.data_ptr() for x_ in ts])
+    x_d, dws, dbs = _nhwc(x), [t(w) for w in ws], [t(b) for b in bs]
+    ds_d = None if ds is None else dev(ds)
+    nel = x.size
+    y = torch.empty(nel, device=DEV)
+    save = [torch.empty(nel, device=DEV) for _ in range(5)]
+    wsb = torch.empty(int(lib.erf_workspace_bytes(N * H * W, C_)), dtype=torch.uint8, device=DEV)
+    fwd = [bn_struct(b) for b in bn_np]
+    _lib.check(lib.erf_nb1d_forward(_dptr(x_d), arr(dws), arr(dbs), C.byref(fwd[0][0]), C.byref(fwd[1][0]),
+                                    None if ds_d is None else _dptr(ds_d), dil, _dptr(y), arr(save), N, C_, H, W,
+                                    _dptr(wsb), wsb.numel(), None))
+    torch.cuda.synchronize()
+    gu.check_arrays(_to_nchw(y, x.shape), y_ref, FWD_ATOL, FWD_RTOL, what="y")
+    for i in (0, 1, 2, 3, 4):
+        gu.check_arrays(_to_nchw(save[i], x.shape), sv[i], FWD_ATOL, FWD_RTOL, what=f"save{i}", scale_rtol=1e-5)
+    if mode == 2:
+        for (st, f, sm, si), o in zip(fwd, obn):
+            gu.check_arrays(sm.cpu().numpy(), o.save_mean, 1e-5, 1e-5, what="batch mean")
+            gu.check_arrays(si.cpu().numpy(), o.save_invstd, 1e-5, 1e-4, what="batch 1/std")
+            gu.check_arrays(f["running_mean"].cpu().numpy(), o.running_mean, 1e-6, 1e-5, what="running_mean")
+            gu.check_arrays(f["running_var"].cpu().numpy(), o.running_var, 1e-6, 1e-5, what="running_var")
+
+    # backward at the oracle's point: its activations, its batch statistics
+    bwd = [bn_struct(b, o.save_mean, o.save_invstd) for b, o in zip(bn_np, obn)]
+    save_ref = [_nhwc(sv[i]) for i in range(5)]
+    y_ref_d, gy_d = _nhwc(y_ref), _nhwc(gy)
+    dx = torch.empty(nel, device=DEV)
+    gdw = [torch.empty(w.size, device=DEV) for w in ws]
+    gdb = [torch.empty(C_, device=DEV) for _ in range(4)]
+    gdg = [torch.empty(C_, device=DEV) for _ in range(2)]
+    gdbt = [torch.empty(C_, device=DEV) for _ in range(2)]
+    _lib.check(lib.erf_nb1d_backward(_dptr(x_d), arr(dws), C.byref(bwd[0][0]), C.byref(bwd[1][0]),
+                                     None if ds_d is None else _dptr(ds_d), dil, _dptr(y_ref_d), arr(save_ref),
+                                     _dptr(gy_d), _dptr(dx), arr(gdw), arr(gdb), arr(gdg), arr(gdbt), N, C_, H, W, 0,
+                                     _dptr(wsb), wsb.numel(), None))
+    torch.cuda.synchronize()
+    gu.check_arrays(_to_nchw(dx, x.shape), dx_ref, 5e-4, 5e-4, what="dx", scale_rtol=2e-4)
+    for i in range(4):
+        gu.check_arrays(gdw[i].cpu().numpy().reshape(ws[i].shape), dws_ref[i], 5e-4, 5e-4, what=f"dw{i}",
+                        scale_rtol=2e-4)
+        # a bias in front of a train-mode BatchNorm has gradient zero up to rounding of large sums
+        gu.check_arrays(gdb[i].cpu().numpy(), dbs_ref[i], 5e-4, 5e-4, what=f"db{i}", scale_rtol=2e-4)
+    for i in range(2):
+        gu.check_arrays(gdg[i].cpu().numpy(), dgs_ref[i], 5e-4, 5e-4, what=f"dgamma{i}", scale_rtol=2e-4)
+        gu.check_arrays(gdbt[i].cpu().numpy(), dbts_ref[i], 5e-4, 5e-4, what=f"dbeta{i}", scale_rtol=2e-4)
 
 
 def test_c_abi_rejects_bad_arguments():
@@ -696,6 +794,68 @@ def test_predict_labels_equals_argmax_of_logits():
     assert lab.dtype == torch.int64 and lab.shape == (2, 1, 64, 96)
     assert torch.equal(lab, logits.max(1)[1].unsqueeze(1))
     assert (lab.cpu() != lab_cpu).float().mean() < 1e-3      # CPU conv rounding may flip near-ties
+
+
+def _golden_label_case(key, size):
+    """(input, golden arg-max map [N,H,W], mask of the pixels whose golden top-2 margin is no tie)."""
+    if size == "fullres":
+        x = gu.det_uniform("net.x_fullres", (1, 3, 1024, 2048), 0.0, 1.0)
+        return x, EXTRA["fullres/argmax_s2"], EXTRA["fullres/margin_s2"].astype(np.float32) > 2.5e-3, 2
+    shape = (1, 3, 64, 128) if size == "small" else (1, 3, 512, 1024)
+    x = gu.det_uniform("net.x_" + size, shape, 0.0, 1.0)
+    gold = NETS[f"{key}/{size}/argmax"]
+    if size == "big":
+        return x, gold, NETS[f"{key}/big/margin"].astype(np.float32) > 2.5e-3, 1
+    return x, gold, None, 1
+
+
+LABEL_CASES = [("eval_erfnet_20", "small"), ("eval_erfnet_nobn_19", "small"), ("eval_erfnet_20", "big"),
+               ("eval_erfnet_nobn_19", "fullres")]
+
+
+@pytest.mark.parametrize("key,size", LABEL_CASES)
+def test_predict_labels_against_golden_argmax(key, size):
+    """ERFNet.predict_labels (the fused output-convolution + arg-max kernel) against the REFERENCE's
+    arg-max map: identical class on every pixel that is not a tie (golden top-2 margin above the
+    logit tolerance; for the small case, which stores no margin, the margin of the HIP logits)."""
+    x, gold, ok, step = _golden_label_case(key, size)
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    with torch.no_grad():
+        lab = net.predict_labels(t(x))
+        if ok is None:
+            top2 = first(net(t(x))).topk(2, dim=1).values
+            ok = ((top2[:, 0] - top2[:, 1]) > 2e-3).cpu().numpy()
+    lab = lab[:, 0, ::step, ::step].cpu().numpy()
+    assert ok.mean() > 0.9
+    assert np.array_equal(lab.astype(np.uint8)[ok], gold[ok])
+    assert (lab.astype(np.uint8) != gold).mean() < 2e-3          # ties included: a handful at most
+
+
+@pytest.mark.parametrize("key,size", LABEL_CASES[2:])
+def test_iou_gate_predicted_labels_score_like_the_reference(key, size):
+    """The evaluation gate end to end (eval/eval_iou.py:90-92 + eval/iouEval.py:21-75): label maps
+    from HIP predict_labels and the reference's arg-max map, both scored by iouEval against the
+    same ground truth (the golden map with 30 % of the pixels relabelled at random, class 19 =
+    ignore).  Per-class IoU must agree within 0.1 (the gate); in practice it agrees to 1e-3."""
+    from erfnet_pytorch_amd.iouEval import iouEval
+    x, gold, _, step = _golden_label_case(key, size)
+    ncls = 20
+    noise = gu.det_labels(f"iougate.{key}.noise", gold.shape, 0, ncls).astype(np.int64)
+    swap = gu.det_uniform(f"iougate.{key}.swap", gold.shape, 0.0, 1.0) < 0.3
+    truth = t(np.where(swap, noise, gold.astype(np.int64))).unsqueeze(1)
+    net = gu.fill_state_dict(make_model(key), tag=key).to(DEV).eval()
+    with torch.no_grad():
+        lab = net.predict_labels(t(x))[:, :, ::step, ::step].contiguous()
+    scores = []
+    for pred in (lab, t(gold.astype(np.int64)).unsqueeze(1)):
+        ev = iouEval(ncls)                      # ignoreIndex 19, as the reference's default
+        ev.addBatch(pred, truth)
+        scores.append(ev.getIoU())
+    (m_hip, c_hip), (m_ref, c_ref) = scores
+    d = (c_hip - c_ref).abs().max().item()
+    assert d <= 0.1 and abs(float(m_hip) - float(m_ref)) <= 0.1
+    assert d <= 1e-3, d
+    assert float(m_ref) > 0.1                   # a real score (random maps would give 1/39 per class)
 
 
 def test_iou_eval_gpu_counts():
