@@ -237,3 +237,13 @@ __device__ __forceinline__ float epi_finish(const Epilogue &e, float v, long lon
     if (e.mask) v = Act<T>::ld1(e.mask, pix * e.mask_C + e.mask_coff + c) > 0.0f ? v : 0.0f;
     return v;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter, i.e. it would wait for the output stores of the tile just finished and for the DMA of the
+// next tile, which are meant to stay in flight across it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}

@@ -84,16 +84,6 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_byte_ad
                                      (void __attribute__((address_space(3))) *)(uintptr_t)lds_byte_addr, 16, 0, 0);
 }
 
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
-// counter, i.e. it would wait for the output stores of the tile just finished and for the DMA of the
-// next tile, which are meant to stay in flight across it.
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
 // bf16 patterns: zero the elements of v whose mask element is not > 0
 __device__ __forceinline__ u32x4 mask_bf16x8(u32x4 v, u32x4 m)
 {

@@ -139,10 +139,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
         }
         store_b(buf, R.b);
     };
+    // Step s multiplies the tiles staged in buffer s & 1.  Its loads were issued two steps earlier
+    // (at step s - 3 into R, stored to LDS at step s - 1), so a load has two whole steps to land;
+    // the barrier orders LDS traffic only and leaves the loads in flight.
     auto step1 = [&](int s, Stage &R) {
         const int buf = s & 1;
         if (s + 1 < NSTEPS) store1(buf ^ 1, R);
-        if (s + 2 < NSTEPS) load1(s + 2, R);
+        if (s + 3 < NSTEPS) load1(s + 3, R);
         const float *Ab = Ts + buf * BM * KC, *Bb = Bs[buf];
 #pragma unroll
         for (int qq = 0; qq < KC / 8; ++qq) {
@@ -159,20 +162,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
                 for (int a = 0; a < WM; ++a)
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[m], acc[a], 0, 0, 0);
         }
-        __syncthreads();
+        lds_barrier();
     };
 
-    Stage st0;
+    static_assert(NSTEPS % 2 == 0, "two register stages alternate");
     {
-        Stage st1;
-        load1(0, st0);
-        load1(1, st1);
-        store1(0, st0);
-        st0 = st1;
+        Stage stA, stB;             // stA: odd steps' tiles, stB: even steps'
+        load1(0, stB);
+        load1(1, stA);
+        store1(0, stB);
+        load1(2, stB);
+        lds_barrier();
+        for (int s = 0; s < NSTEPS; s += 2) {
+            step1(s, stA);
+            step1(s + 1, stB);
+        }
     }
-    __syncthreads();
-#pragma unroll 2
-    for (int s = 0; s < NSTEPS; ++s) step1(s, st0);
 
     // ------------------------------------------------------------------ epilogues
     // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -259,17 +264,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
     epilogue(d.epi1, sc1, sh1, (NS > 1 && blockIdx.y != 0) ? nullptr : d.mid, true,
              std::integral_constant<int, WM>{}, wm, col);
     store_b2(0, wb0);
-#pragma unroll
-    for (int i = 0; i < B_PASSES2; ++i) wb0[i] = wb1[i];
+    load_w2(2, wb0);
     clear_acc();
     __syncthreads();
 
     // ------------------------------------------------------------------ conv_b: A = mid tile in LDS
-#pragma unroll 2
-    for (int s = 0; s < NSTEPS; ++s) {
+    // (weight tiles two steps ahead, as above: wb1 feeds the odd steps, wb0 the even ones)
+    auto step2 = [&](int s, f32x4 *wreg) {
         const int buf = s & 1;
-        if (s + 1 < NSTEPS) store_b2(buf ^ 1, wb0);
-        if (s + 2 < NSTEPS) load_w2(s + 2, wb0);
+        if (s + 1 < NSTEPS) store_b2(buf ^ 1, wreg);
+        if (s + 3 < NSTEPS) load_w2(s + 3, wreg);
         const int t = s / KCH, kc = s % KCH;
         const int sh = t == 0 ? s2a : (t == 1 ? s2b : s2c);
         const float *Bb = Bs[buf];
@@ -295,7 +299,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
                 for (int a = 0; a < WM2; ++a)
                     acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][m], bf[m], acc[a], 0, 0, 0);
         }
-        __syncthreads();
+        lds_barrier();
+    };
+    for (int s = 0; s < NSTEPS; s += 2) {
+        step2(s, wb1);
+        step2(s + 1, wb0);
     }
     epilogue(d.epi2, sc2, sh2, d.out, false, std::integral_constant<int, WM2>{}, wm2, col2);
 }
