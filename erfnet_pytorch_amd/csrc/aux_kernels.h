@@ -947,3 +947,161 @@ __global__ __launch_bounds__(256) void outconv_wreduce_kernel(const float *parti
         db[idx - nw] = tot;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Backward of CrossEntropyLoss(ignore_index) THROUGH the output ConvTranspose2d in one pass: the
+// gradient of the logits, (softmax - onehot) * gy / n_labelled, is formed in registers from the
+// block input x (the logits are recomputed: 16 x 4*ncls products per input pixel), and feeds the
+// data gradient and the weight gradient at once; it never reaches memory.  Separate kernels write
+// and read that tensor (N x ncls x 2H x 2W floats, the largest of the network) three times.
+//
+// All three products run on v_mfma_f32_16x16x4_f32 (lane (i, g) = (lane & 15, lane >> 4) supplies
+// A[i][g] and B[g][i], receives D[4g + r][i]).  A wave takes 16 input pixels at a time, pixel = i:
+//   logits  D[oab][pixel] = sum_c W[c][oab] x[pixel][c]        k <-> channel 4g + kk, kk = 0..3
+//           -> lane holds class o = 4T + g, positions ab = r = 0..3 of tile T
+//   G       = (exp(logit - lse) - [o == target]) * scale       in that layout
+//   dx      D[c][pixel] = sum_oab W[c][oab] G[oab][pixel]      k <-> oab = 16T + 4g + r: G as held
+//   dW      D[c][oab] = sum_pixel x[pixel][c] G[pixel][oab]    k <-> pixel: G and x go through a
+//           per-wave LDS tile to put the pixel into the contraction position
+// Partial dW / db leave the block in the slab format of outconv_wgrad_kernel.
+struct OutConvCeDesc {
+    const void *x;              // NHWC [N][H][W][16], storage type T
+    const float *w, *b;         // [16][ncls][2][2], [ncls] or null
+    const long long *target;    // [N][2H][2W]
+    const float *lse;           // [N][2H][2W] log-sum-exp of the logits (saved by the loss forward)
+    const float *stats, *gy;    // stats[1] = labelled pixels; gy = gradient of the scalar loss
+    void *dx;                   // NHWC like x, or null
+    float *partial;
+    int N, H, W, ncls, mask_dx;
+    long long ignore_index;
+    unsigned groups, gpb;       // 16-pixel groups in total / per block
+};
+
+template <int NT, typename T>
+__global__ __launch_bounds__(256) void outconv_ce_bwd_kernel(const OutConvCeDesc d)
+{
+    constexpr int PG = NT * 16 + ((NT * 16) % 64 == 0 ? 16 : 0);       // row pitch of the G tile
+    __shared__ __attribute__((aligned(16))) float Gs[4][16 * PG];
+    __shared__ __attribute__((aligned(16))) float Xs[4][16 * 16];
+    __shared__ float red[4][NT * 256 + NT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int nab = d.ncls * 4;
+    const unsigned HW = (unsigned)d.H * d.W, M = (unsigned)d.N * HW;
+    const unsigned Ho = 2 * d.H, Wo = 2 * d.W;
+
+    // weights in the two operand layouts, bias of this lane's classes
+    float wa[NT][4], wd[NT][4], bo[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int oab_a = 16 * t + i;
+        const int o = 4 * t + g;
+        bo[t] = (o < d.ncls && d.b) ? d.b[o] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            wa[t][e] = oab_a < nab ? d.w[(4 * g + e) * nab + oab_a] : 0.0f;
+            wd[t][e] = o < d.ncls ? d.w[i * nab + 16 * t + 4 * g + e] : 0.0f;
+        }
+    }
+    const float scale = d.gy[0] / d.stats[1];
+
+    f32x4 accw[NT];
+    float bsum[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { accw[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; bsum[t] = 0.0f; }
+    float *gs = Gs[wave], *xs = Xs[wave];
+
+    const unsigned g0 = blockIdx.x * d.gpb;
+    unsigned g1 = g0 + d.gpb;
+    if (g1 > d.groups) g1 = d.groups;
+    for (unsigned grp = g0 + wave; grp < g1; grp += 4) {
+        const unsigned m = grp * 16 + i;
+        const bool valid = m < M;
+        const unsigned mm = valid ? m : 0;
+        const unsigned n = mm / HW, rem = mm - n * HW;
+        const unsigned y = rem / d.W, x = rem - y * d.W;
+        f32x4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (valid) xq = Act<T>::ld4(d.x, (long long)mm * OC_CIN + 4 * g);
+        const long long ob = ((long long)n * Ho + 2 * y) * Wo + 2 * x;
+        float lse[4];
+        long long tg[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const f32x2 l2 = *reinterpret_cast<const f32x2 *>(d.lse + ob + (long long)a * Wo);
+            lse[2 * a] = l2[0]; lse[2 * a + 1] = l2[1];
+            tg[2 * a] = d.target[ob + (long long)a * Wo];
+            tg[2 * a + 1] = d.target[ob + (long long)a * Wo + 1];
+        }
+        // logits of classes 4T + g at the four output positions of pixel i
+        f32x4 lg[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) lg[t] = f32x4{bo[t], bo[t], bo[t], bo[t]};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) lg[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][kk], xq[kk], lg[t], 0, 0, 0);
+        // gradient of the logits
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool lab = valid && tg[r] != d.ignore_index && tg[r] >= 0 && tg[r] < d.ncls;
+            const float s = lab ? scale : 0.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int o = 4 * t + g;
+                const float p = __expf(lg[t][r] - lse[r]) - ((long long)o == tg[r] ? 1.0f : 0.0f);
+                lg[t][r] = (lab && o < d.ncls) ? p * s : 0.0f;
+            }
+        }
+        // data gradient (two accumulators: the dependent latency of the instruction exceeds its issue time)
+        if (d.dx) {
+            f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][0], lg[t][0], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][1], lg[t][1], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][2], lg[t][2], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][3], lg[t][3], a1, 0, 0, 0);
+            }
+            f32x4 v = a0 + a1;
+            if (d.mask_dx) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xq[e] > 0.0f ? v[e] : 0.0f;
+            }
+            if (valid) Act<T>::st4(d.dx, (long long)mm * OC_CIN + 4 * g, v);
+        }
+        // weight gradient: pixel into the contraction position through the wave's LDS tile
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(&gs[i * PG + 16 * t + 4 * g]) = lg[t];
+        *reinterpret_cast<f32x4 *>(&xs[i * 16 + 4 * g]) = xq;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const float xa = xs[(4 * kk + g) * 16 + i];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float gb = gs[(4 * kk + g) * PG + 16 * t + i];
+                bsum[t] += gb;
+                accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, gb, accw[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // D[row = c = 4g + r][col = oab = 16T + i]; bias sums over the pixel index g
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(16 * t + i) * 16 + 4 * g + r] = accw[t][r];
+        float bs = bsum[t];
+        bs += __shfl_xor(bs, 16);
+        bs += __shfl_xor(bs, 32);
+        if (g == 0) red[wave][NT * 256 + 16 * t + i] = bs;
+    }
+    __syncthreads();
+    float *P = d.partial + (long long)blockIdx.x * (nab * OC_CIN + nab);
+    for (int idx = tid; idx < nab * OC_CIN; idx += 256)
+        P[idx] = red[0][idx] + red[1][idx] + red[2][idx] + red[3][idx];
+    for (int idx = tid; idx < nab; idx += 256) {
+        const int e = NT * 256 + idx;
+        P[nab * OC_CIN + idx] = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    }
+}

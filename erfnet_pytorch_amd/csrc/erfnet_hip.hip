@@ -1828,6 +1828,41 @@ static int outconv_backward_impl(int dt, const void *x, const float *w, const fl
     return 0;
 }
 
+// CrossEntropyLoss backward fused into the output transposed convolution's backward
+static int outconv_ce_backward_impl(int dt, const void *x, const float *w, const float *b, const long long *target,
+                                    const float *lse, const float *stats, const float *gy, void *dx, float *dw,
+                                    float *db, int N, int Cin, int H, int W, int ncls, long long ignore_index,
+                                    int flags, void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (Cin != OC_CIN) return fail("output ConvTranspose2d: Cin must be %d (got %d)", OC_CIN, Cin);
+    if (ncls < 1 || ncls > OC_MAX_NCLS) return fail("output ConvTranspose2d: 1 <= classes <= %d", OC_MAX_NCLS);
+    if (!x || !w || !target || !lse || !stats || !gy || !dw) return fail("output ConvTranspose2d + loss backward: null pointer");
+    if (!aligned16(x) || (dx && !aligned16(dx)) || ((uintptr_t)lse & 7) || ((uintptr_t)target & 7))
+        return fail("output ConvTranspose2d + loss backward: misaligned tensors");
+    const long long M = (long long)N * H * W;
+    if (M == 0) return fail("output ConvTranspose2d + loss backward: empty input");
+    if (M * OC_CIN >= (1LL << 29) || M * 4 * ncls >= (1LL << 29))
+        return fail("output ConvTranspose2d backward: tensors of 2 GiB or more are not supported");
+    const int nab = ncls * 4, slab = nab * OC_CIN + nab;
+    const long long groups = (M + 15) / 16;
+    long long nblk = 4LL * cu_count();
+    long long gpb = (groups + nblk - 1) / nblk;
+    gpb = (gpb + 3) / 4 * 4;                    // whole rounds of the four waves
+    nblk = (groups + gpb - 1) / gpb;
+    float *partial = ar.floats((size_t)nblk * slab);
+    if (!partial) return fail("output ConvTranspose2d + loss backward: workspace too small");
+    OutConvCeDesc d = {x, w, b, target, lse, stats, gy, dx, partial, N, H, W, ncls, (flags & ERF_BWD_MASK_DX) ? 1 : 0,
+                       ignore_index, (unsigned)groups, (unsigned)gpb};
+    if (ncls <= 20) BY_DT(dt, (outconv_ce_bwd_kernel<5, T><<<(unsigned)nblk, 256, 0, st>>>(d)));
+    else BY_DT(dt, (outconv_ce_bwd_kernel<8, T><<<(unsigned)nblk, 256, 0, st>>>(d)));
+    CHECK_LAUNCH("outconv_ce_bwd_kernel");
+    outconv_wreduce_kernel<<<(slab + 31) / 32, 256, 0, st>>>(partial, dw, db, (int)nblk, ncls);
+    CHECK_LAUNCH("outconv_wreduce_kernel");
+    return 0;
+}
+
 // ================================================================================ plain Conv2d
 static void conv2d_taps(int k, int *dh, int *dw, int *woff, bool transpose)
 {
@@ -2253,6 +2288,22 @@ int erf_outconv_forward_bf16(const void *x, const float *w, const float *b, void
 {
     return outconv_forward_impl(ERF_DT_BF16, y_is_bf16 ? ERF_DT_BF16 : ERF_DT_F32, x, w, b, y, N, Cin, H, W, ncls,
                                 softmax, stream);
+}
+int erf_outconv_ce_backward(const float *x, const float *w, const float *b, const long long *target,
+                            const float *lse, const float *stats, const float *gy, float *dx, float *dw, float *db,
+                            int N, int Cin, int H, int W, int ncls, long long ignore_index, int flags, void *ws,
+                            size_t ws_bytes, void *stream)
+{
+    return outconv_ce_backward_impl(ERF_DT_F32, x, w, b, target, lse, stats, gy, dx, dw, db, N, Cin, H, W, ncls,
+                                    ignore_index, flags, ws, ws_bytes, stream);
+}
+int erf_outconv_ce_backward_bf16(const void *x, const float *w, const float *b, const long long *target,
+                                 const float *lse, const float *stats, const float *gy, void *dx, float *dw,
+                                 float *db, int N, int Cin, int H, int W, int ncls, long long ignore_index, int flags,
+                                 void *ws, size_t ws_bytes, void *stream)
+{
+    return outconv_ce_backward_impl(ERF_DT_BF16, x, w, b, target, lse, stats, gy, dx, dw, db, N, Cin, H, W, ncls,
+                                    ignore_index, flags, ws, ws_bytes, stream);
 }
 int erf_outconv_argmax(const float *x, const float *w, const float *b, long long *labels, int N, int Cin,
                        int H, int W, int ncls, void *stream)

@@ -634,9 +634,41 @@ def upsampler(x, w, b, bn_weight=None, bn_bias=None, running_mean=None, running_
 
 
 # ------------------------------------------------------------------------------ output ConvTranspose2d
+# Loss hand-over.  The logits are the largest tensor of the network and their gradient would be
+# written by the loss and read twice by the output convolution's backward.  While autograd records,
+# the logits carry a token; CrossEntropyLoss2d's backward deposits what defines its gradient
+# (targets, log-sum-exp, label count, upstream scalar) in the token and hands autograd a stride-0
+# view of a zero scalar instead of the gradient; the output convolution's backward finds the deposit
+# and runs one fused kernel (erf_outconv_ce_backward).  Because the stand-in is zero, gradients that
+# other consumers of the logits add to it (the mean-teacher consistency loss, train/main.py:353)
+# stay correct: the convolution then sees a tensor that is not the stand-in, materialises the
+# deposited loss gradients and takes the ordinary path.  What does NOT see the loss gradient is
+# code that asks autograd for the gradient of the logits themselves (torch.autograd.grad(loss,
+# logits), logits.retain_grad() after the loss was built): call set_loss_handover(False) for that.
+_LOSS_HANDOVER = True
+
+
+def set_loss_handover(enabled):
+    """Switch the loss hand-over (see above) on or off; returns the previous setting."""
+    global _LOSS_HANDOVER
+    old, _LOSS_HANDOVER = _LOSS_HANDOVER, bool(enabled)
+    return old
+
+
+class _LossToken:
+    __slots__ = ("pending", "zero")
+
+    def __init__(self, device):
+        self.pending = []
+        self.zero = torch.zeros((), dtype=torch.float32, device=device)
+
+    def is_stand_in(self, g):
+        return g.data_ptr() == self.zero.data_ptr() and all(s == 0 for s in g.stride())
+
+
 class _OutConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, loss_token):
         lib = _lib.lib()
         ctx.in_token = _input_token(x)
         x = _nhwc(x)
@@ -645,30 +677,51 @@ class _OutConv(torch.autograd.Function):
         wq, bq = _param(w), _param(b)
         y = _outconv_call(x, wq, bq, n, cin, h, wd, ncls, 0, False)
         if any(ctx.needs_input_grad):
-            ctx.save_for_backward(x, wq)
+            ctx.save_for_backward(x, wq, bq)
             ctx.has_bias = b is not None
             ctx.params = (w, b)
+            ctx.loss_token = loss_token
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = _lib.lib()
-        x, wq = ctx.saved_tensors
+        x, wq, bq = ctx.saved_tensors
         n, cin, h, wd = x.shape
         ncls = wq.shape[1]
-        gy = gy.contiguous()
-        if gy.dtype != torch.float32:
-            gy = gy.float()
+        tok = ctx.loss_token
+        pending = []
+        if tok is not None:
+            pending, tok.pending = tok.pending, []
+        fused = len(pending) == 1 and tok.is_stand_in(gy)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         tg = _grad_targets(ctx.params, (wq.shape, (ncls,)), x.device)
         dw, db = tg[0][0], tg[1][0]
         ws = _workspace(x, n * h * wd, 16)
         flags = _lib.BWD_MASK_DX if (ctx.in_token is not None and dx is not None) else 0
-        with _dev_ctx(x):
-            _lib.check(_fn("erf_outconv_backward", x)(_p(x), _p(wq), _p(gy), _p(dx), _p(dw), _p(db), n, cin, h,
-                                                      wd, ncls, flags, _p(ws), ws.numel(), _stream(x)))
+        if fused:
+            target, lse, stats, gl, ignore_index, _ = pending[0]
+            with _dev_ctx(x):
+                _lib.check(_fn("erf_outconv_ce_backward", x)(_p(x), _p(wq), _p(bq), _p(target), _p(lse), _p(stats),
+                                                             _p(gl), _p(dx), _p(dw), _p(db), n, cin, h, wd, ncls,
+                                                             ignore_index, flags, _p(ws), ws.numel(), _stream(x)))
+        else:
+            if pending:
+                # other gradients were added to the stand-in (or several losses deposited): the
+                # deposited loss gradients are materialised and summed with what autograd delivered
+                total = None if tok.is_stand_in(gy) else gy.float()
+                for target, lse, stats, gl, ignore_index, logits in pending:
+                    g = _cross_entropy_grad(logits, target, lse, stats, gl, ignore_index)
+                    total = g if total is None else total + g
+                gy = total
+            gy = gy.contiguous()
+            if gy.dtype != torch.float32:
+                gy = gy.float()
+            with _dev_ctx(x):
+                _lib.check(_fn("erf_outconv_backward", x)(_p(x), _p(wq), _p(gy), _p(dx), _p(dw), _p(db), n, cin, h,
+                                                          wd, ncls, flags, _p(ws), ws.numel(), _stream(x)))
         dw, db = _match_params(_deliver(tg), ctx.params)
-        return _hand_over(ctx, dx), dw, (db if ctx.has_bias else None)
+        return _hand_over(ctx, dx), dw, (db if ctx.has_bias else None), None
 
 
 def _outconv_call(x, wq, bq, n, cin, h, wd, ncls, softmax, bf16_out):
@@ -694,7 +747,11 @@ def outconv(x, w, b):
     being built (they feed the loss), bf16 under torch.no_grad() (half the bytes of the largest
     tensor of the network)."""
     if torch.is_grad_enabled():
-        return _OutConv.apply(x, w, b)
+        tok = _LossToken(x.device) if _LOSS_HANDOVER else None
+        y = _OutConv.apply(x, w, b, tok)
+        if tok is not None and y.requires_grad:
+            y._erf_loss_token = tok
+        return y
     x = _nhwc(x)
     n, cin, h, wd = x.shape
     return _outconv_call(x, _param(w), _param(b), n, cin, h, wd, w.shape[1], 0, x.dtype == torch.bfloat16)
@@ -793,19 +850,31 @@ class _CrossEntropy(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x, tg, lse, stats)
             ctx.ignore_index = int(ignore_index)
+            tok = getattr(logits, "_erf_loss_token", None) if _LOSS_HANDOVER else None
+            # the hand-over needs the very tensor the output convolution produced
+            ctx.loss_token = tok if (tok is not None and x.data_ptr() == logits.data_ptr()
+                                     and not logits.retains_grad) else None
         return stats[0]
 
     @staticmethod
     def backward(ctx, gy):
-        lib = _lib.lib()
         x, tg, lse, stats = ctx.saved_tensors
-        n, k, h, wd = x.shape
         gy = gy.to(torch.float32).reshape(1).contiguous()
-        dx = torch.empty_like(x)
-        with _dev_ctx(x):
-            _lib.check(lib.erf_cross_entropy_backward(_p(x), _p(tg), _p(lse), _p(stats), _p(gy), _p(dx),
-                                                      n, k, h, wd, ctx.ignore_index, _stream(x)))
-        return dx, None, None
+        tok = ctx.loss_token
+        if tok is not None and _LOSS_HANDOVER:
+            tok.pending.append((tg, lse, stats, gy, ctx.ignore_index, x))
+            return tok.zero.expand(x.shape), None, None
+        return _cross_entropy_grad(x, tg, lse, stats, gy, ctx.ignore_index), None, None
+
+
+def _cross_entropy_grad(x, tg, lse, stats, gy, ignore_index):
+    lib = _lib.lib()
+    n, k, h, wd = x.shape
+    dx = torch.empty_like(x)
+    with _dev_ctx(x):
+        _lib.check(lib.erf_cross_entropy_backward(_p(x), _p(tg), _p(lse), _p(stats), _p(gy), _p(dx),
+                                                  n, k, h, wd, ignore_index, _stream(x)))
+    return dx
 
 
 def cross_entropy(logits, target, ignore_index=-1):

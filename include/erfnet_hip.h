@@ -177,6 +177,15 @@ int erf_outconv_argmax(const float *x, const float *w, const float *b, long long
 int erf_outconv_backward(const float *x, const float *w, const float *gy, float *dx, float *dw,
                          float *db, int N, int Cin, int H, int W, int ncls, int flags, void *ws,
                          size_t ws_bytes, void *stream);
+/* Backward of erf_cross_entropy_forward THROUGH the output convolution, for the training loop's
+ * `criterion(model(x), targets).backward()` (train/main.py:333,379): equals erf_cross_entropy_backward
+ * followed by erf_outconv_backward, but the gradient of the logits is formed in registers (logits
+ * recomputed from x) and never written.  target / lse / stats as erf_cross_entropy_forward received
+ * and produced them for the logits of this x, w, b; gy: device scalar, gradient of the loss. */
+int erf_outconv_ce_backward(const float *x, const float *w, const float *b, const long long *target,
+                            const float *lse, const float *stats, const float *gy, float *dx, float *dw,
+                            float *db, int N, int Cin, int H, int W, int ncls, long long ignore_index,
+                            int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- plain nn.Conv2d on NHWC tensors (Encoder.output_conv 1x1, eval/erfnet.py:85,93-94;
  *      LadderBlock's 3x3 conv, train/erfnet_blocks.py:145,151-154) -----------------------------
@@ -322,6 +331,10 @@ int erf_outconv_argmax_bf16(const void *x, const float *w, const float *b, long 
 int erf_outconv_backward_bf16(const void *x, const float *w, const float *gy, void *dx, float *dw,
                               float *db, int N, int Cin, int H, int W, int ncls, int flags, void *ws,
                               size_t ws_bytes, void *stream);
+int erf_outconv_ce_backward_bf16(const void *x, const float *w, const float *b, const long long *target,
+                                 const float *lse, const float *stats, const float *gy, void *dx, float *dw,
+                                 float *db, int N, int Cin, int H, int W, int ncls, long long ignore_index,
+                                 int flags, void *ws, size_t ws_bytes, void *stream);
 int erf_conv2d_forward_bf16(const void *x, const float *w, const float *b, void *y, int N, int Cin,
                             int H, int W, int Cout, int k, int relu, void *ws, size_t ws_bytes,
                             void *stream);

@@ -542,6 +542,60 @@ def test_relu_mask_hand_over_leaves_gradients_unchanged(key, monkeypatch):
     assert torch.equal(xa, xb) and torch.equal(xa2, xb) and torch.equal(xb2, xb)
 
 
+def _loss_head_run(mode, dtype=torch.float32, ncls=20, shape=(2, 16, 24, 40)):
+    """Output convolution + loss on seeded inputs; mode selects how the logits are consumed."""
+    from erfnet_pytorch_amd import functional as hipf
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d, MSELossWeighted
+    n, c, h, w = shape
+    x = t(np.maximum(gu.det_normal("losshead.x", shape), 0)).to(dtype).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    wt = t(0.3 * gu.det_normal("losshead.w", (16, ncls, 2, 2))).requires_grad_(True)
+    b = t(0.1 * gu.det_normal("losshead.b", (ncls,))).requires_grad_(True)
+    lab = t(gu.det_labels("losshead.lab", (n, 2 * h, 2 * w), -1, ncls))
+    other = t(gu.det_normal("losshead.other", (n, ncls, 2 * h, 2 * w)))
+    n0 = launches()
+    y = hipf.outconv(x, wt, b)
+    loss = CrossEntropyLoss2d()(y, lab)
+    if mode == "scaled":
+        loss = loss * 0.37
+    elif mode == "two_consumers":          # mean-teacher: the same logits feed the consistency loss
+        loss = loss + MSELossWeighted(2.0)(y, other, 0.5)
+    elif mode == "two_losses":
+        loss = loss + 0.5 * CrossEntropyLoss2d()(y, lab.flip(0))
+    loss.backward(retain_graph=(mode == "twice"))
+    if mode == "twice":
+        first = [v.grad.clone() for v in (x, wt, b)]
+        for v in (x, wt, b):
+            v.grad = None
+        loss.backward()
+        for u, v in zip(first, (x, wt, b)):
+            assert torch.equal(u, v.grad)
+    return float(loss.detach()), [v.grad.float().cpu().numpy() for v in (x, wt, b)], launches() - n0
+
+
+@pytest.mark.parametrize("mode", ["plain", "scaled", "two_consumers", "two_losses", "twice"])
+@pytest.mark.parametrize("dtype,ncls", [(torch.float32, 20), (torch.float32, 7), (torch.float32, 29),
+                                        (torch.bfloat16, 20)])
+def test_loss_hand_over_matches_separate_kernels(mode, dtype, ncls):
+    """CrossEntropyLoss2d's backward fused into the output convolution's (erf_outconv_ce_backward, the
+    gradient of the logits never written) against the separate kernels: same loss, gradients equal
+    up to the rounding of a recomputed logit — also when the logits have a second consumer, two
+    losses, an upstream scale, or the graph is walked twice."""
+    from erfnet_pytorch_amd import functional as hipf
+    fused = _loss_head_run(mode, dtype, ncls)
+    old = hipf.set_loss_handover(False)
+    try:
+        plain = _loss_head_run(mode, dtype, ncls)
+    finally:
+        hipf.set_loss_handover(old)
+    assert fused[0] == plain[0]
+    if mode in ("plain", "scaled"):
+        assert fused[2] < plain[2]          # fewer launches: the fused kernel really ran
+    tol = 2e-5 if dtype == torch.float32 else 1e-2      # bf16: dx is rounded to bf16 on both sides
+    for nm, u, v in zip(("dx", "dw", "db"), fused[1], plain[1]):
+        gu.check_arrays(u, v, 1e-7, 1e-5, what=f"{mode}/{nm}", scale_rtol=tol)
+
+
 def test_graphed_forward_replays_the_eager_result():
     """A forward captured into a HIP graph (graphs.GraphedForward) returns bit-identical logits on
     replay, for the captured input and for new data of the same shape."""
