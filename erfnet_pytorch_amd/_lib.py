@@ -101,6 +101,8 @@ _PROTOS = {
                                       C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_cross_entropy_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ll, vp,
                                             C.c_size_t, vp]),
+    "erf_cross_entropy_forward_counts": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ll, vp,
+                                                   C.c_size_t, vp]),
     "erf_cross_entropy_forward_static": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, ll, vp]),
     "erf_accuracy_counts": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),
     "erf_iou_add_batch": (C.c_int, [vp, vp, ll, C.c_int, C.c_int, vp, vp, C.c_size_t, vp]),

@@ -1938,9 +1938,9 @@ static int conv2d_backward_impl(int dt, const void *x, const float *w, const voi
 }
 
 // ================================================================================ CrossEntropyLoss2d
-int erf_cross_entropy_forward(const float *logits, const long long *target, float *stats, float *lse,
-                              int N, int K, int H, int W, long long ignore_index, void *ws,
-                              size_t ws_bytes, void *stream)
+static int cross_entropy_forward_impl(const float *logits, const long long *target, float *stats, float *lse,
+                                      long long *counts, int N, int K, int H, int W, long long ignore_index, void *ws,
+                                      size_t ws_bytes, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
@@ -1949,15 +1949,38 @@ int erf_cross_entropy_forward(const float *logits, const long long *target, floa
     if (P == 0) return fail("cross entropy: empty input");
     const long long blocks = (P + CE_BLOCK - 1) / CE_BLOCK;
     if (blocks >= (1LL << 31)) return fail("cross entropy: too many pixels");
+    if (counts && K > CE_MAX_K) return fail("cross entropy with accuracy counts: at most %d classes (got %d)", CE_MAX_K, K);
     float *partial = ar.floats((size_t)blocks * 2);
-    if (!partial) return fail("cross entropy: workspace too small");
-    CeDesc d = {logits, target, lse, partial, P, H * W, K, ignore_index};
+    unsigned *cpartial = counts ? (unsigned *)ar.take((size_t)blocks * 2 * K * sizeof(unsigned)) : nullptr;
+    if (!partial || (counts && !cpartial)) return fail("cross entropy: workspace too small");
+    CeDesc d = {logits, target, lse, partial, P, H * W, K, ignore_index, cpartial};
     if (K <= CE_MAX_K) ce_fwd_kernel<true><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     else ce_fwd_kernel<false><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     CHECK_LAUNCH("ce_fwd_kernel");
     ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
     CHECK_LAUNCH("ce_reduce_kernel");
+    if (counts) {
+        ce_count_sum_kernel<<<2 * K, 256, 0, st>>>(cpartial, (int)blocks, 2 * K, counts);
+        CHECK_LAUNCH("ce_count_sum_kernel");
+    }
     return 0;
+}
+
+int erf_cross_entropy_forward(const float *logits, const long long *target, float *stats, float *lse,
+                              int N, int K, int H, int W, long long ignore_index, void *ws,
+                              size_t ws_bytes, void *stream)
+{
+    return cross_entropy_forward_impl(logits, target, stats, lse, nullptr, N, K, H, W, ignore_index, ws, ws_bytes,
+                                      stream);
+}
+
+int erf_cross_entropy_forward_counts(const float *logits, const long long *target, float *stats, float *lse,
+                                     long long *counts, int N, int K, int H, int W, long long ignore_index,
+                                     void *ws, size_t ws_bytes, void *stream)
+{
+    if (!counts) return fail("cross entropy with accuracy counts: null pointer");
+    return cross_entropy_forward_impl(logits, target, stats, lse, counts, N, K, H, W, ignore_index, ws, ws_bytes,
+                                      stream);
 }
 
 // ---- the same loss for callers that may not allocate (static scratch, see the top of the file)
@@ -1979,7 +2002,7 @@ int erf_cross_entropy_forward_static(const float *logits, const long long *targe
     if (static_scratch(&sp)) return 1;
     // every block overwrites its own pair of partial sums before the reduction reads them, so
     // nothing of an earlier call's contents has to be cleared
-    CeDesc d = {logits, target, lse, (float *)sp, P, H * W, K, ignore_index};
+    CeDesc d = {logits, target, lse, (float *)sp, P, H * W, K, ignore_index, nullptr};
     if (K <= CE_MAX_K) ce_fwd_kernel<true><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     else ce_fwd_kernel<false><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     CHECK_LAUNCH("ce_fwd_kernel");

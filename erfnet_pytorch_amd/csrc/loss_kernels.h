@@ -21,12 +21,20 @@ struct CeDesc {
     long long P;                // N * HW
     int HW, K;
     long long ignore_index;
+    unsigned *cpartial;         // optional (K <= CE_MAX_K): [blocks][2][K] correct / labelled pixels per label class
 };
 
 template <bool SMALL_K>
 __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const CeDesc d)
 {
     __shared__ float red[2][CE_BLOCK / 64];
+    // accuracy counts on the side: the arg-max class is known once the class values are in registers
+    __shared__ unsigned hist[2 * CE_MAX_K];
+    const bool counting = SMALL_K && d.cpartial != nullptr;
+    if (counting) {
+        if (threadIdx.x < 2 * CE_MAX_K) hist[threadIdx.x] = 0;
+        __syncthreads();
+    }
     const long long p = (long long)blockIdx.x * CE_BLOCK + threadIdx.x;
     float loss = 0.0f, cnt = 0.0f;
     if (p < d.P) {
@@ -47,6 +55,19 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const CeDesc d)
 #pragma unroll
             for (int k = 0; k < CE_MAX_K; ++k) s += k < d.K ? __expf(v[k] - m) : 0.0f;
             lse = m + __logf(s);
+            if (counting && t >= 0 && t < d.K) {
+                // first largest value, NaN wins: torch's argmax
+                float best = v[0];
+                int arg = 0;
+#pragma unroll
+                for (int k = 1; k < CE_MAX_K; ++k) {
+                    const bool take = k < d.K && (v[k] > best || (v[k] != v[k] && best == best));
+                    best = take ? v[k] : best;
+                    arg = take ? k : arg;
+                }
+                atomicAdd(&hist[d.K + (int)t], 1u);
+                if (arg == (int)t) atomicAdd(&hist[(int)t], 1u);
+            }
         } else {
             float m = -INFINITY;
             for (int k = 0; k < d.K; ++k) m = fmaxf(m, x[(long long)k * d.HW]);
@@ -78,6 +99,25 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const CeDesc d)
         d.partial[2 * (long long)blockIdx.x + 0] = a;
         d.partial[2 * (long long)blockIdx.x + 1] = b;
     }
+    if (counting) {         // (the barrier above also orders the LDS atomics)
+        if (threadIdx.x < 2 * d.K) d.cpartial[(long long)blockIdx.x * 2 * d.K + threadIdx.x] = hist[threadIdx.x];
+    }
+}
+
+// counts[j] = sum over blocks of cpartial[block][j], j < 2K: one block per column, exact integers.
+__global__ __launch_bounds__(256) void ce_count_sum_kernel(const unsigned *cpartial, int nblocks, int J, long long *counts)
+{
+    __shared__ long long red[256];
+    const int j = blockIdx.x;
+    long long s = 0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += cpartial[(long long)i * J + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[j] = red[0];
 }
 
 // stats[0] = mean loss, stats[1] = number of labelled pixels.  One block, fixed summation order

@@ -122,7 +122,12 @@ class MSELossWeighted(torch.nn.Module):
 
 def _accuracy_counts(prob, targets):
     """int64 [2][K] on the device: per label class, correctly classified pixels and labelled pixels
-    (one pass of erf_accuracy_counts over the scores, no argmax tensor, no per-class loop)."""
+    (one pass of erf_accuracy_counts over the scores, no argmax tensor, no per-class loop; no pass
+    at all when the loss has already been evaluated on the same tensors, as in train/main.py:327-347)."""
+    cached = getattr(prob, "_erf_acc_cache", None)
+    if cached is not None and cached[:4] == (targets.data_ptr(), targets._version, tuple(targets.shape),
+                                             prob._version) and targets.dtype == torch.int64:
+        return cached[4]            # CrossEntropyLoss2d counted them while it read these very tensors
     lib = _lib.lib()
     n, k, h, w = prob.shape
     scores = prob.detach()

@@ -844,9 +844,20 @@ class _CrossEntropy(torch.autograd.Function):
         stats = torch.empty(2, dtype=torch.float32, device=x.device)
         lse = torch.empty((n, h, wd), dtype=torch.float32, device=x.device)
         ws = _workspace(x, n * h * wd, 1)
+        # With the reference's ignore_index (-1: exactly the negative labels are unlabelled) the same
+        # pass also counts what its accuracy metrics need; they find the counts on the logits.
+        counts = torch.empty((2, k), dtype=torch.int64, device=x.device) if (k <= 32 and int(ignore_index) == -1) \
+            else None
         with _dev_ctx(x):
-            _lib.check(lib.erf_cross_entropy_forward(_p(x), _p(tg), _p(stats), _p(lse), n, k, h, wd,
-                                                     int(ignore_index), _p(ws), ws.numel(), _stream(x)))
+            if counts is None:
+                _lib.check(lib.erf_cross_entropy_forward(_p(x), _p(tg), _p(stats), _p(lse), n, k, h, wd,
+                                                         int(ignore_index), _p(ws), ws.numel(), _stream(x)))
+            else:
+                _lib.check(lib.erf_cross_entropy_forward_counts(_p(x), _p(tg), _p(stats), _p(lse), _p(counts), n, k,
+                                                                h, wd, int(ignore_index), _p(ws), ws.numel(),
+                                                                _stream(x)))
+                logits._erf_acc_cache = (target.data_ptr(), target._version, tuple(target.shape), logits._version,
+                                         counts)
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x, tg, lse, stats)
             ctx.ignore_index = int(ignore_index)

@@ -208,6 +208,14 @@ int erf_conv2d_backward(const float *x, const float *w, const float *y, const fl
 int erf_cross_entropy_forward(const float *logits, const long long *target, float *stats, float *lse,
                               int N, int K, int H, int W, long long ignore_index, void *ws,
                               size_t ws_bytes, void *stream);
+/* The same, and in the same pass over the logits the counts behind the reference's accuracy metrics
+ * (ClassificationAccuracy / MeanAccuracy, train/evaluation_functions.py:133-163, which train/main.py:343-347
+ * evaluates on the tensors the loss has just read): counts int64 [2][K] is OVERWRITTEN with, per label
+ * class, the pixels whose arg-max class (first largest) equals the label, and the pixels carrying
+ * that label.  K <= 32. */
+int erf_cross_entropy_forward_counts(const float *logits, const long long *target, float *stats, float *lse,
+                                     long long *counts, int N, int K, int H, int W, long long ignore_index,
+                                     void *ws, size_t ws_bytes, void *stream);
 /* The same loss for callers that cannot allocate device memory or bring a workspace: code under HIP
  * graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
  * reference.  The block partial sums go to a 1 MiB array inside the library's code object (one

@@ -835,6 +835,33 @@ def test_accuracy_metrics_match_reference_formulas():
         assert abs(float(mean_acc) - float(np.nanmean(ref_cls))) < 1e-6
 
 
+def test_loss_forward_leaves_accuracy_counts_for_the_metrics():
+    """train/main.py:327-347 evaluates the loss and then both accuracy metrics on the same
+    (logits, targets): the loss kernel counts on the side, the metrics launch nothing, and the
+    values equal those of the stand-alone metric kernel; a changed tensor invalidates the counts."""
+    from erfnet_pytorch_amd.evaluation_functions import ClassificationAccuracy, CrossEntropyLoss2d, MeanAccuracy
+    g = torch.Generator().manual_seed(9)
+    prob = torch.randn(2, 20, 48, 80, generator=g)
+    tgt = torch.randint(-1, 18, (2, 48, 80), generator=g)
+    prob = prob + 6.0 * torch.nn.functional.one_hot(tgt.clamp(min=0), 20).permute(0, 3, 1, 2) * \
+        (torch.rand(2, 1, 48, 80, generator=g) < 0.5)
+    prob, tgt = prob.to(DEV), tgt.to(DEV)
+    ref_acc = ClassificationAccuracy()(prob, tgt)
+    ref_mean, ref_cls = MeanAccuracy(20)(prob, tgt)
+    loss = CrossEntropyLoss2d()(prob, tgt)
+    n0 = launches()
+    acc = ClassificationAccuracy()(prob, tgt)
+    mean, cls = MeanAccuracy(20)(prob, tgt)
+    assert launches() == n0
+    assert float(acc) == float(ref_acc) and float(mean) == float(ref_mean)
+    np.testing.assert_array_equal(cls, ref_cls)
+    assert abs(float(loss) - float(torch.nn.functional.cross_entropy(prob, tgt, ignore_index=-1))) < 1e-5
+    tgt[0, 0, 0] = 3                                   # in-place change: the counts are stale
+    n0 = launches()
+    ClassificationAccuracy()(prob, tgt)
+    assert launches() - n0 == 2
+
+
 def test_predict_labels_equals_argmax_of_logits():
     """ERFNet.predict_labels (erf_outconv_argmax) against max(1)[1] of the logits of the same
     network: identical labels, int64 [N,1,H,W]; the CPU path agrees as well."""
