@@ -30,7 +30,7 @@ class BnStruct(C.Structure):
     """Mirror of ``erf_bn_t``."""
     _fields_ = [("mode", C.c_int), ("gamma", vp), ("beta", vp), ("running_mean", vp),
                 ("running_var", vp), ("save_mean", vp), ("save_invstd", vp),
-                ("momentum", C.c_float), ("eps", C.c_float)]
+                ("momentum", C.c_float), ("eps", C.c_float), ("num_batches_tracked", vp)]
 
 
 class Nb1dBlockStruct(C.Structure):

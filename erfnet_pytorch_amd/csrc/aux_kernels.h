@@ -433,15 +433,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const double *partial, d
 }
 
 // mean / invstd from the sums; running statistics updated as nn.BatchNorm2d does in training
-// (momentum, unbiased variance).
-__global__ void bn_finalize_kernel(const double *sums, float *save_mean, float *save_invstd,
-                                   float *run_mean, float *run_var, long long M, int C, float momentum,
-                                   float eps)
+// (momentum, unbiased variance, step counter).
+__device__ __forceinline__ void bn_finalize_channel(double sum, double sumsq, int c, float *save_mean, float *save_invstd,
+                                                    float *run_mean, float *run_var, long long M, float momentum,
+                                                    float eps)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mean = sums[c] / (double)M;
-    double var = sums[C + c] / (double)M - mean * mean;
+    const double mean = sum / (double)M;
+    double var = sumsq / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
     save_mean[c] = (float)mean;
     save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -450,6 +448,45 @@ __global__ void bn_finalize_kernel(const double *sums, float *save_mean, float *
         const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
         run_var[c] = (float)((1.0 - momentum) * run_var[c] + momentum * unb);
     }
+}
+
+__global__ void bn_finalize_kernel(const double *sums, float *save_mean, float *save_invstd,
+                                   float *run_mean, float *run_var, long long *nbt, long long M, int C,
+                                   float momentum, float eps)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    bn_finalize_channel(sums[c], sums[C + c], c, save_mean, save_invstd, run_mean, run_var, M, momentum, eps);
+}
+
+// bn_reduce_kernel for both sums of a channel followed by the finalisation, in one launch: a block
+// takes 8 channels x 32 row groups; the additions run in bn_reduce_kernel's order.
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double *partial, int G, float *save_mean,
+                                                                 float *save_invstd, float *run_mean, float *run_var,
+                                                                 long long *nbt, long long M, int C, float momentum,
+                                                                 float eps)
+{
+    __shared__ double red[2][32][9];
+    const int e = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + e;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int i = g; i < G; i += 32) {
+            a += partial[(long long)i * 2 * C + c];
+            b += partial[(long long)i * 2 * C + C + c];
+        }
+    }
+    red[0][g][e] = a;
+    red[1][g][e] = b;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+    if (g != 0 || c >= C) return;
+    double s0 = red[0][0][e], s1 = red[1][0][e];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) { s0 += red[0][k][e]; s1 += red[1][k][e]; }
+    bn_finalize_channel(s0, s1, c, save_mean, save_invstd, run_mean, run_var, M, momentum, eps);
 }
 
 // Eval mode needs mean/invstd in the same form for backward.

@@ -960,13 +960,29 @@ int bn_train_stats(int dt, const erf_bn_t *bn, const void *pre, long long M, int
 {
     if (C > 256) return fail("BatchNorm kernels support C <= 256 (C = %d)", C);
     if (!bn->save_mean || !bn->save_invstd) return fail("BatchNorm train mode needs save_mean/save_invstd");
+    if (C % 4 == 0 && aligned16(pre)) {
+        // per-block partial rows, then one launch that adds them in a fixed order and finalises
+        const int G = bn_stats_blocks(M, C);
+        double *partial = (double *)ar.take(sizeof(double) * 2 * (size_t)C * G);
+        if (!partial) return fail("workspace too small for BatchNorm partial sums");
+        BnStatsDesc s = {pre, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, M, C, 1, 2048};
+        BnStats4Desc d4 = {s, partial};
+        BY_DT(dt, (bn_stats4_kernel<false, T><<<G, 256, 0, st>>>(d4)));
+        CHECK_LAUNCH("bn_stats4_kernel");
+        bn_reduce_finalize_kernel<<<(C + 7) / 8, 256, 0, st>>>(partial, G, bn->save_mean, bn->save_invstd,
+                                                              bn->running_mean, bn->running_var,
+                                                              bn->num_batches_tracked, M, C, bn->momentum, bn->eps);
+        CHECK_LAUNCH("bn_reduce_finalize_kernel");
+        return 0;
+    }
     double *sums = (double *)ar.take(sizeof(double) * 2 * C);
     if (!sums) return fail("workspace too small for BatchNorm sums");
     const int rows = 2048;
     BnStatsDesc s = {pre, nullptr, nullptr, nullptr, nullptr, nullptr, sums, M, C, 1, rows};
     if (bn_stats_launch(dt, s, false, ar, st)) return 1;
     bn_finalize_kernel<<<(C + 63) / 64, 64, 0, st>>>(sums, bn->save_mean, bn->save_invstd, bn->running_mean,
-                                                    bn->running_var, M, C, bn->momentum, bn->eps);
+                                                    bn->running_var, bn->num_batches_tracked, M, C, bn->momentum,
+                                                    bn->eps);
     CHECK_LAUNCH("bn_finalize_kernel");
     return 0;
 }

@@ -32,11 +32,18 @@ def _bn_mode(module, enabled):
 
 
 def _bn_args(bn):
-    return bn.weight, bn.bias, bn.running_mean, bn.running_var
+    """The tensors of a BatchNorm2d for the library.  num_batches_tracked travels as an attribute of
+    running_mean: the library's statistics kernel adds 1 to it in a train-mode forward, as
+    nn.BatchNorm2d.forward does (no separate launch per layer)."""
+    rm, nbt = bn.running_mean, bn.num_batches_tracked
+    if rm is not None:
+        rm._erf_nbt = nbt if (nbt is not None and nbt.is_cuda and nbt.dtype == torch.int64) else None
+    return bn.weight, bn.bias, rm, bn.running_var
 
 
 def _bn_tick(bn, mode):
-    if mode == 2 and bn.num_batches_tracked is not None:
+    """Counter update for the cases the library did not cover (counter not an int64 GPU tensor)."""
+    if mode == 2 and bn.num_batches_tracked is not None and getattr(bn.running_mean, "_erf_nbt", None) is None:
         bn.num_batches_tracked += 1
 
 

@@ -130,8 +130,11 @@ class _Bn:
             c = gamma.numel()
             self.save_mean = torch.empty(c, dtype=torch.float32, device=gamma.device)
             self.save_invstd = torch.empty(c, dtype=torch.float32, device=gamma.device)
+        # nn.BatchNorm2d's step counter rides on the running_mean tensor (erfnet_blocks._bn_args);
+        # the statistics kernel of a train-mode forward increments it
+        self.nbt = getattr(running_mean, "_erf_nbt", None) if self.mode == 2 else None
         self.struct = BnStruct(self.mode, _p(self.gamma), _p(self.beta), _p(self.rm), _p(self.rv),
-                               _p(self.save_mean), _p(self.save_invstd), self.momentum, self.eps)
+                               _p(self.save_mean), _p(self.save_invstd), self.momentum, self.eps, _p(self.nbt))
 
     def ref(self):
         return C.byref(self.struct) if self.mode else None

@@ -34,13 +34,15 @@ extern "C" {
  * mode 1: eval, normalise with running stats
  * mode 2: train, batch statistics; running_mean/var are updated in place (momentum, unbiased
  *         variance); save_mean/save_invstd ([C] each) receive the batch statistics for backward.
- * In modes 1 and 2 save_mean/save_invstd must be valid when a backward call will follow. */
+ * In modes 1 and 2 save_mean/save_invstd must be valid when a backward call will follow.
+ * num_batches_tracked: optional device int64 (nn.BatchNorm2d's counter); a mode-2 forward adds 1. */
 typedef struct {
     int mode;
     const float *gamma, *beta;
     float *running_mean, *running_var;
     float *save_mean, *save_invstd;
     float momentum, eps;
+    long long *num_batches_tracked;
 } erf_bn_t;
 
 /* Library identification / diagnostics. */

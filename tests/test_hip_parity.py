@@ -108,6 +108,8 @@ def test_block_against_golden(name, monkeypatch):
         for k, b in mod.named_buffers():
             if k.endswith("running_mean") or k.endswith("running_var"):
                 chk_fwd(name, f"buf:{k}", b.cpu().numpy())
+            if k.endswith("num_batches_tracked") and (c["kind"] != "nb1d" or build_block(c).use_batchnorm):
+                assert int(b) == 1, k       # counted by the statistics kernel, once per forward
 
 
 def test_conv1x1_against_golden():
