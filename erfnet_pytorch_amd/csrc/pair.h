@@ -39,6 +39,14 @@ __device__ __forceinline__ int mid_swz(int row, int chunk)
     return chunk ^ ((row & 7) | ((((row >> 3) ^ (row >> 2)) & 1) << 3));
 }
 
+// Weight tile in LDS: [channel][16 k] floats, the four 16-byte chunks of a row permuted by the row
+// index so that both the staging stores (a wave writes 1 KiB contiguous) and the fragment reads
+// (lanes = 16 consecutive rows, one chunk each) touch every bank once.
+__device__ __forceinline__ int bs_off(int row, int chunk)
+{
+    return row * 16 + ((chunk ^ ((row >> 2) & 3)) << 2);
+}
+
 // NW = waves per block: 4 for launches that fill the chip (three resident blocks per CU), 8 when
 // there are fewer lines than CU slots (small batches), where a block's own latency sets the time.
 // NS = 2 (very small launches): two blocks per line; both run the first convolution in full, each
@@ -48,7 +56,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
 {
     constexpr int NC2 = NC / NS, GN2 = NC2 / 32, GM2 = NW / GN2, WM2 = BM / (32 * GM2);
     static_assert(GM2 >= 1 && WM2 >= 1 && GM2 * WM2 * 32 == BM, "tile shape of the second convolution");
-    constexpr int KC = 16, CPR = KC / 4, BPITCH = KC + 4, NT = NW * 64, KCH = NC / KC;
+    constexpr int KC = 16, CPR = KC / 4, BPITCH = KC, NT = NW * 64, KCH = NC / KC;
     constexpr int GN = NC / 32, GM = NW / GN, WM = BM / (32 * GM);
     static_assert(GM >= 1 && WM >= 1 && GM * WM * 32 == BM, "tile shape");
     constexpr int A_SLOTS = BM * CPR, B_SLOTS = NC * CPR;
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
         for (int i = 0; i < B_PASSES; ++i) {
             const int slot = tid + i * NT;
             if (B_FULL || slot < B_SLOTS)
-                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = b[i];
+                *reinterpret_cast<f32x4 *>(&Bs[buf][bs_off(slot / CPR, slot % CPR)]) = b[i];
         }
     };
     auto store1 = [&](int buf, const Stage &R) {
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
                 const int row = (wm * WM + a) * 32 + l31;
                 af[a] = *reinterpret_cast<const f32x4 *>(&Ab[row * KC + (((2 * qq + h) ^ ((row >> 2) & 3)) << 2)]);
             }
-            bf = *reinterpret_cast<const f32x4 *>(&Bb[col * BPITCH + qq * 8 + h * 4]);
+            bf = *reinterpret_cast<const f32x4 *>(&Bb[bs_off(col, 2 * qq + h)]);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -256,7 +264,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
         for (int i = 0; i < B_PASSES2; ++i) {
             const int slot = tid + i * NT;
             if (B_FULL2 || slot < B_SLOTS2)
-                *reinterpret_cast<f32x4 *>(&Bs[buf][(slot / CPR) * BPITCH + (slot % CPR) * 4]) = b[i];
+                *reinterpret_cast<f32x4 *>(&Bs[buf][bs_off(slot / CPR, slot % CPR)]) = b[i];
         }
     };
     load_w2(0, wb0);
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 1 : (BM * NC <= 8192 ? 3 : 2)))
 #pragma unroll
             for (int a = 0; a < WM2; ++a)
                 af[a] = *reinterpret_cast<const f32x4 *>(arow[a] + (((kc * CPR + 2 * qq + h) ^ asw[a]) << 2));
-            bf = *reinterpret_cast<const f32x4 *>(&Bb[colb * BPITCH + qq * 8 + h * 4]);
+            bf = *reinterpret_cast<const f32x4 *>(&Bb[bs_off(colb, 2 * qq + h)]);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll

@@ -1,4 +1,5 @@
 set -e
-timeout -k 10 60 python scripts/micro_pair.py --c 128 --h 64 --w 128 --d 2 --reps 50 --axis 0
-timeout -k 10 60 python scripts/micro_pair.py --c 64 --h 128 --w 256 --d 1 --reps 50 --axis 0
-timeout -k 10 60 python scripts/micro_pair.py --c 128 --h 64 --w 128 --d 2 --reps 50 --axis 1
+timeout -k 10 120 python scripts/fwd_fullres.py 1 bf16
+ERFNET_NO_PAIR=1 timeout -k 10 120 python scripts/fwd_fullres.py 1 bf16
+timeout -k 10 120 python scripts/fwd_fullres.py 4 bf16
+ERFNET_NO_PAIR=1 timeout -k 10 120 python scripts/fwd_fullres.py 4 bf16
