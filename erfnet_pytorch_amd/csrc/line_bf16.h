@@ -144,9 +144,11 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
     const bool res_first = PAIR && d.epi1.res != nullptr;
     const bool has_res = res_first || (PAIR ? d.epi2.res : d.epi1.res) != nullptr;
 
+    // (every lambda below is forced inline: an outlined one makes the accumulators it captures by
+    // reference live in scratch memory, which costs a memory round trip per MFMA)
     // tile index -> geometry (wave-uniform)
     struct Geo { int q; unsigned base; int r0, len; };
-    auto geo = [&](int tile) {
+    auto geo = [&](int tile) __attribute__((always_inline)) {
         Geo g;
         const int line = tile / d.segs, seg = tile - line * d.segs;
         const int n = line / d.lines_per_img;
@@ -156,11 +158,11 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
         g.base = (unsigned)n * d.img_pixels + (unsigned)g.q * d.qstride + (unsigned)g.r0 * d.pstride;
         return g;
     };
-    auto tap_shift = [&](int t) { return t == 0 ? s1a : (t == 1 ? s1b : s1c); };
-    auto tap_valid = [&](const Geo &g, int t) { return (unsigned)(g.q + tap_shift(t)) < (unsigned)d.lines_per_img; };
+    auto tap_shift = [&](int t) __attribute__((always_inline)) { return t == 0 ? s1a : (t == 1 ? s1b : s1c); };
+    auto tap_valid = [&](const Geo &g, int t) __attribute__((always_inline)) { return (unsigned)(g.q + tap_shift(t)) < (unsigned)d.lines_per_img; };
 
     // LDS-DMA of one line tile (rows beyond the line repeat its last row: their products are dropped)
-    auto issue_tile = [&](const bf16_t *src, unsigned pixel0, int len, int dst_off) {
+    auto issue_tile = [&](const bf16_t *src, unsigned pixel0, int len, int dst_off) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             const int slot = p * 256 + tid;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
         for (int i = tid; i < PITCH / 4; i += 256) reinterpret_cast<unsigned *>(lds + OFF_MID + T)[i] = 0u;
 
     f32x16 acc[WM];
-    auto clear_acc = [&]() {
+    auto clear_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
     // The fragments of k-step s+1 are read while the MFMAs of step s run (the compiler, left alone,
     // waits for every read right in front of its MFMA: with one wave per SIMD nothing else hides the
     // LDS latency).
-    auto mma_tap = [&](const bf16x8 (&w)[KS], const unsigned char *const (&rowp)[WM], const unsigned (&x4)[WM]) {
+    auto mma_tap = [&](const bf16x8 (&w)[KS], const unsigned char *const (&rowp)[WM], const unsigned (&x4)[WM]) __attribute__((always_inline)) {
         constexpr int D = WM >= 4 ? 2 : 3;      // fragment sets: reads run D - 1 k-steps ahead of their MFMAs
         bf16x8 xf[D][WM];
 #pragma unroll
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
 
     // Coalesced pass over a finished LDS tile (bf16, swizzled): [mask by a global tensor, written back
     // to the tile when `keep`] -> [global store].  Four 16-byte chunks per thread are in flight at a time.
-    auto sweep_tile = [&](int lds_off, const bf16_t *mk, bf16_t *dst, bool keep, const Geo &g) {
+    auto sweep_tile = [&](int lds_off, const bf16_t *mk, bf16_t *dst, bool keep, const Geo &g) __attribute__((always_inline)) {
         constexpr int B = PASSES % 4 == 0 ? 4 : (PASSES % 2 == 0 ? 2 : 1);
 #pragma unroll
         for (int p0 = 0; p0 < PASSES; p0 += B) {
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
     // (the three switches are compile-time: evaluated per element they cost more instructions than
     // the arithmetic itself, and with one wave per SIMD nothing overlaps an epilogue)
     auto store_acc_t = [&](auto relu_t, auto scale_t, auto res_t, const float *sc_, const float *sh_, bool zero_dead,
-                           int dst_off, const Geo &g) {
+                           int dst_off, const Geo &g) __attribute__((always_inline)) {
         constexpr bool RELU = decltype(relu_t)::value, SCALE = decltype(scale_t)::value, RES = decltype(res_t)::value;
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         const bool ragged = zero_dead && g.len < BM;          // wave-uniform
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
         }
     };
     auto store_acc = [&](const Epilogue &e, const float *sc_, const float *sh_, bool add_res, bool zero_dead,
-                         int dst_off, const Geo &g) {
+                         int dst_off, const Geo &g) __attribute__((always_inline)) {
         using T1 = std::true_type;
         using T0 = std::false_type;
         const int key = (e.relu ? 4 : 0) | (e.bn.on ? 2 : 0) | (add_res ? 1 : 0);
@@ -344,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void line_bf16_kernel(const LineDesc d)
 
     // Final epilogue of a tile: accumulators (+ residual) -> RES tile (in place of the residual), then
     // a coalesced pass [mask] -> global.
-    auto finish_tile = [&](const Epilogue &e, const float *sc_, const float *sh_, bf16_t *dst, const Geo &g) {
+    auto finish_tile = [&](const Epilogue &e, const float *sc_, const float *sh_, bf16_t *dst, const Geo &g) __attribute__((always_inline)) {
         store_acc(e, sc_, sh_, has_res && !res_first, false, OFF_RES, g);
         lds_barrier();
         sweep_tile(OFF_RES, (const bf16_t *)e.mask, dst, false, g);

@@ -42,6 +42,25 @@ def run(n, c, h, w, first_axis, d1, d2, keep_mid, res, iters=50):
           f"{flop / us * 1e-6:7.1f} TFLOP/s  {byts / us * 1e-3:7.1f} GB/s alg")
 
 
+CASES_IMAGENET = [
+    (256, 128, 28, 28, 1, 1, 2, True, False),
+    (256, 128, 28, 28, 1, 1, 2, True, True),
+    (256, 128, 28, 28, 0, 1, 0, False, False),
+    (256, 64, 56, 56, 1, 1, 1, True, False),
+    (32, 128, 28, 28, 1, 1, 2, True, False),
+    (256, 128, 28, 28, 1, 1, 2, False, False),
+    (256, 128, 32, 32, 1, 1, 2, True, False),
+    (256, 128, 28, 32, 1, 1, 2, True, False),
+    (256, 128, 32, 28, 1, 1, 2, True, False),
+    (64, 128, 64, 28, 1, 1, 2, True, False),
+    (256, 128, 28, 28, 0, 1, 2, True, False),
+    (256, 128, 28, 28, 1, 1, 1, True, False),
+]
+if len(sys.argv) > 1 and sys.argv[1] == "imagenet":
+    for args in CASES_IMAGENET:
+        run(*args, iters=10)
+    sys.exit(0)
+
 for args in [
     (6, 128, 64, 128, 1, 1, 2, False, True),
     (6, 128, 64, 128, 1, 1, 2, True, True),
