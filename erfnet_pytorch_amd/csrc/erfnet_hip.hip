@@ -7,6 +7,7 @@
 #include "sampler16.h"
 #include "pair.h"
 #include "line_bf16.h"
+#include "igemm_bf16.h"
 #include "wgrad_line.h"
 #include "wgrad_line_bf16.h"
 #include "loss_kernels.h"
@@ -288,6 +289,23 @@ bool stream16_ok(const IgemmDesc &d)
     return true;
 }
 
+// bf16 tensors on the bf16 MFMA (igemm_bf16_kernel): tiles {pixels, channels} and its requirements.
+// ERFNET_NO_IGEMM_BF16=1 keeps bf16 tensors on the fp32 MFMA (experiments).
+const int kCfgBf16 = 200;
+const TileCfg kCfgB[] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}, {128, 32}};
+bool igemm_bf16_ok(const IgemmDesc &d)
+{
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("ERFNET_NO_IGEMM_BF16"); off = (e && atoi(e)) ? 1 : 0; }
+    if (!d.dt || off) return false;
+    if (d.K % 8 || d.in_C % 8 || d.in_coff % 8 || !aligned16(d.in)) return false;
+    if (d.Nout % 4 || d.out_C % 4 || d.out_coff % 4 || ((uintptr_t)d.out & 7)) return false;
+    if (d.epi.res && (d.epi.res_C % 4 || d.epi.res_coff % 4 || ((uintptr_t)d.epi.res & 7))) return false;
+    if (d.epi.mask && (d.epi.mask_C % 4 || d.epi.mask_coff % 4 || ((uintptr_t)d.epi.mask & 7))) return false;
+    if (d.epi.nscale && !aligned16(d.epi.nscale)) return false;
+    return true;
+}
+
 // Validate, choose the tile, reserve the packed-weight buffer and describe the packing job.
 int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
 {
@@ -323,6 +341,32 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
         d.cfg = kCfgStream16;
         d.Npad = 16;
         memset(&pk, 0, sizeof(pk));
+        return 0;
+    }
+    if (igemm_bf16_ok(d)) {         // bf16 tensors: bf16 MFMA, bf16 packed weights
+        const int first = d.Nout > 64 ? 0 : (d.Nout > 32 ? 2 : 4), count = d.Nout > 32 ? 2 : 1;
+        int best = first;
+        long long best_cost = -1;
+        for (int c = first; c < first + count; ++c) {
+            const long long blocks = (M + kCfgB[c].bm - 1) / kCfgB[c].bm;
+            const long long cost = ((blocks + 255) / 256) * kCfgB[c].bm;
+            if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+        }
+        d.cfg = kCfgBf16 + best;
+        const int bn = kCfgB[best].bn;
+        d.Npad = (d.Nout + bn - 1) / bn * bn;
+        int ntaps = 0;
+        for (int g = 0; g < d.ngroups; ++g) ntaps = d.gtap0[g] + d.gntaps[g] > ntaps ? d.gtap0[g] + d.gntaps[g] : ntaps;
+        const int kchunks = (d.K + 31) / 32;
+        const size_t n = (size_t)ntaps * kchunks * d.Npad * 32;
+        void *wp = ar.take(n * sizeof(bf16_t));
+        if (!wp) return fail("igemm: workspace too small for the packed weights (%zu bf16)", n);
+        d.wp = wp;
+        memset(&pk, 0, sizeof(pk));
+        pk.w = d.w; pk.wp = (float *)wp; pk.bf16 = 1;
+        pk.ntaps = ntaps; pk.K = d.K; pk.Nout = d.Nout; pk.Npad = d.Npad; pk.wsk = d.wsk; pk.wsn = d.wsn;
+        pk.kc = 32;
+        for (int t = 0; t < ERF_MAX_TAPS; ++t) pk.woff[t] = d.woff[t];
         return 0;
     }
     if (!d.vec_ok) d.cfg = 8;
@@ -402,6 +446,19 @@ int run_igemm_t(const IgemmDesc &d, hipStream_t st)
         else if (grp >= 2) conv16_kernel<T, 3, 4, 2><<<(unsigned)((M + 511) / 512), 256, 0, st>>>(d);
         else conv16_kernel<T, 3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
         CHECK_LAUNCH("conv16_kernel");
+        return 0;
+    }
+    if (d.cfg >= kCfgBf16) {
+        const TileCfg c = kCfgB[d.cfg - kCfgBf16];
+        dim3 grid((unsigned)((M + c.bm - 1) / c.bm), d.Npad / c.bn, d.ngroups);
+        switch (d.cfg - kCfgBf16) {
+        case 0: igemm_bf16_kernel<2, 2, 2, 2, 2><<<grid, 256, 0, st>>>(d); break;
+        case 1: igemm_bf16_kernel<1, 2, 2, 2, 2><<<grid, 256, 0, st>>>(d); break;
+        case 2: igemm_bf16_kernel<2, 1, 2, 2, 2><<<grid, 256, 0, st>>>(d); break;
+        case 3: igemm_bf16_kernel<1, 1, 2, 2, 2><<<grid, 256, 0, st>>>(d); break;
+        default: igemm_bf16_kernel<1, 1, 4, 1, 2><<<grid, 256, 0, st>>>(d); break;
+        }
+        CHECK_LAUNCH("igemm_bf16_kernel");
         return 0;
     }
     const TileCfg c = kCfg[d.cfg];

@@ -41,6 +41,7 @@ struct PackDesc {
     int woff[ERF_MAX_TAPS];
     int line;                                  // 1 = bf16 MFMA fragments for the line kernel (K = Nout = 64 / 128) into lwp
     bf16_t *lwp;
+    int bf16;                                  // 1 = wp receives bf16 values (igemm_bf16_kernel), same order
 };
 #define ERF_PACK_BATCH 32
 struct PackBatch {
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackBatch b)
         const int k = kc * KC + kk;
         float v = 0.0f;
         if (k < d.K && j < d.Nout) v = d.w[d.woff[t] + (long long)k * d.wsk + (long long)j * d.wsn];
-        d.wp[idx] = v;
+        if (d.bf16) reinterpret_cast<bf16_t *>(d.wp)[idx] = f32_to_bf16(v);
+        else d.wp[idx] = v;
     }
 }
 

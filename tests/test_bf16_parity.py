@@ -194,7 +194,9 @@ def test_whole_net_small_bf16(key):
         y = first(net(x))
     assert y.dtype == BF
     y = y.float().cpu().numpy()
-    gu.check(NETS, f"{key}/small/y", y, 1e-5, 0.0, what=f"{key} bf16 logits", scale_rtol=1e-2)
+    # the same bound as for the large inputs below: 1e-2 of the scale, a tail of 1e-3 of the elements within 3e-2
+    gu.check(NETS, f"{key}/small/y", y, 1e-5, 0.0, what=f"{key} bf16 logits", scale_rtol=1e-2, outlier_frac=1e-3,
+             outlier_rtol=3e-2)
     if y.shape[1] > 1:
         g = NETS[f"{key}/small/y"] if f"{key}/small/y" in NETS else None
         if g is not None:
