@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -29,14 +30,15 @@ std::atomic<unsigned long long> g_launches{0};
 // erf_set_option overrides them at run time (A/B tests in one process).
 struct Switch {
     std::atomic<int> v{-1};
-    const char *off_env;
-    explicit Switch(const char *env) : off_env(env) {}
+    const char *off_env;        // the variable that flips the default
+    int dflt;
+    explicit Switch(const char *env, int default_on = 1) : off_env(env), dflt(default_on) {}
     bool on()
     {
         int x = v.load(std::memory_order_relaxed);
         if (x < 0) {
             const char *e = getenv(off_env);
-            x = (e && atoi(e)) ? 0 : 1;
+            x = (e && atoi(e)) ? 1 - dflt : dflt;
             v.store(x, std::memory_order_relaxed);
         }
         return x != 0;
@@ -49,6 +51,9 @@ struct Switch {
     }
 };
 Switch g_sw_pair("ERFNET_NO_PAIR"), g_sw_wgrad_line("ERFNET_NO_WGRAD_LINE"), g_sw_stream16("ERFNET_NO_STREAM16");
+// off by default: measured 5-12 % slower than two conv16_kernel launches (both are issue-bound, not
+// memory-bound, at 16 channels); ERFNET_PAIR16=1 or ERF_OPT_PAIR16 turns it on
+Switch g_sw_pair16("ERFNET_PAIR16", 0);
 
 int fail(const char *fmt, ...)
 {
@@ -442,6 +447,17 @@ int run_igemm_t(const IgemmDesc &d, hipStream_t st)
         static int forced = -1;
         if (forced < 0) { const char *e = getenv("ERFNET_CONV16_G"); forced = e ? atoi(e) : 0; }
         const int grp = forced ? forced : (M >= 3072LL * 256 ? 4 : (M >= 3072LL * 128 ? 2 : 1));
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            // bf16 MFMA variant (16-byte operand loads): the weights are rounded to bf16 as in every other bf16 kernel
+            static int no16 = -1;
+            if (no16 < 0) { const char *e = getenv("ERFNET_NO_CONV16_BF16"); no16 = (e && atoi(e)) ? 1 : 0; }
+            if (!no16 && d.in_C % 8 == 0 && d.in_coff % 8 == 0 && aligned16(d.in)) {
+                if (grp >= 2) conv16_bf16_kernel<8, 2><<<(unsigned)((M + 1023) / 1024), 256, 0, st>>>(d);
+                else conv16_bf16_kernel<8, 1><<<(unsigned)((M + 511) / 512), 256, 0, st>>>(d);
+                CHECK_LAUNCH("conv16_bf16_kernel");
+                return 0;
+            }
+        }
         if (grp >= 4) conv16_kernel<T, 3, 4, 4><<<(unsigned)((M + 1023) / 1024), 256, 0, st>>>(d);
         else if (grp >= 2) conv16_kernel<T, 3, 4, 2><<<(unsigned)((M + 511) / 512), 256, 0, st>>>(d);
         else conv16_kernel<T, 3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
@@ -509,12 +525,56 @@ int pair_tile(int NC, int L)
     return 0;
 }
 
+// Two chained 16-channel convolutions (pair16_kernel): each as conv16_kernel takes it, one along
+// each image axis, the second reaching at most 4 pixels.
+const int kPair16 = 16;
+bool pair16_side_ok(const IgemmDesc &d, const IgemmDesc &a)
+{
+    if (d.K != 16 || d.Nout != 16 || d.ss != 1 || d.os != 1 || d.ngroups != 1 || d.GW < 16) return false;
+    if (d.gtap0[0] != 0 || d.gntaps[0] != 3 || d.goa[0] || d.gob[0]) return false;
+    if (d.N != a.N || d.GH != a.GH || d.GW != a.GW || d.in_H != a.GH || d.in_W != a.GW || d.out_H != a.GH ||
+        d.out_W != a.GW) return false;
+    if (d.in_C % 4 || d.in_coff % 4 || !aligned16(d.in)) return false;
+    if (d.out_C % 4 || d.out_coff % 4 || !aligned16(d.out)) return false;
+    if (d.epi.res && (d.epi.res_C % 4 || d.epi.res_coff % 4 || !aligned16(d.epi.res))) return false;
+    if (d.epi.mask && (d.epi.mask_C % 4 || d.epi.mask_coff % 4 || !aligned16(d.epi.mask))) return false;
+    if (d.epi.bias && !aligned16(d.epi.bias)) return false;
+    if (d.epi.nscale && !aligned16(d.epi.nscale)) return false;
+    if (d.epi.bn.on && (!d.epi.bn.gamma || !d.epi.bn.beta || !aligned16(d.epi.bn.gamma) || !aligned16(d.epi.bn.beta) ||
+                        !aligned16(d.epi.bn.mean) || !aligned16(d.epi.bn.var))) return false;
+    const long long lim = 1LL << 29, px = (long long)d.N * d.GH * d.GW;
+    if (px * d.in_C >= lim || px * d.out_C >= lim) return false;
+    if (d.epi.res && px * d.epi.res_C >= lim) return false;
+    if (d.epi.mask && px * d.epi.mask_C >= lim) return false;
+    return true;
+}
+// 0 = no; else fills the axis / reach of the second convolution
+bool pair16_ok(const IgemmDesc &a, const IgemmDesc &b, int *b_along_w = nullptr, int *halo = nullptr)
+{
+    if (!stream16_enabled() || !g_sw_pair16.on() || a.dt != b.dt) return false;
+    if (!pair16_side_ok(a, a) || !pair16_side_ok(b, a)) return false;
+    if (b.in != a.out || a.out_C != 16 || a.out_coff || b.in_C != 16 || b.in_coff) return false;
+    bool a_w = true, a_h = true, b_w = true, b_h = true;
+    int reach = 0;
+    for (int t = 0; t < 3; ++t) {
+        a_w = a_w && a.tdh[t] == 0; a_h = a_h && a.tdw[t] == 0;
+        b_w = b_w && b.tdh[t] == 0; b_h = b_h && b.tdw[t] == 0;
+        const int r = abs(b.tdh[t]) + abs(b.tdw[t]);
+        reach = r > reach ? r : reach;
+    }
+    if (!((a_w && b_h) || (a_h && b_w)) || reach < 1 || reach > 4) return false;
+    if (b_along_w) *b_along_w = (a_h && b_w) ? 1 : 0;
+    if (halo) *halo = reach;
+    return true;
+}
+
 // a = first convolution, b = second (b.in is a.out).  Returns the tile variant or 0.
 int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = false)
 {
     if (!ignore_switch && !pair_enabled()) return 0;
     const int NC = a.K;
     if (a.dt != b.dt) return 0;
+    if (pair16_ok(a, b)) return kPair16;
     if (a.dt) {          // bf16: both halves must fit the line kernel, the second running along the first's lines
         LineDesc la, lb;
         if (!line_geometry(a, la) || !line_geometry(b, lb, false) || b.in != a.out || b.K != NC) return 0;
@@ -552,8 +612,10 @@ int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = fa
 // A fused pair as planned: the fp32 kernel's descriptor, or the bf16 line kernel's.
 struct FusedPair {
     int dt;
+    int p16_on;             // 1 = the 16-channel kernel (either storage type)
     PairDesc pd;
     LineDesc ld;
+    Pair16Desc p16;
 };
 
 int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, PackDesc pk[2], FusedPair &fp)
@@ -563,6 +625,22 @@ int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, 
     fp.dt = a.dt;
     if (b.out == a.in || (keep_mid && a.out == a.in))
         return fail("conv pair: the output must not alias the input (other blocks still read it)");
+    fp.p16_on = 0;
+    {
+        int along_w = 0, halo = 0;
+        if (pair16_ok(a, b, &along_w, &halo)) {
+            Pair16Desc &q = fp.p16;
+            q.a = a; q.b = b;
+            q.keep_mid = keep_mid ? 1 : 0;
+            q.b_along_w = along_w; q.halo = halo;
+            q.th = along_w ? 8 : 16; q.tw = along_w ? 64 : 32;
+            q.tiles_h = (a.GH + q.th - 1) / q.th; q.tiles_w = (a.GW + q.tw - 1) / q.tw;
+            memset(&pk[0], 0, sizeof(PackDesc));        // torch's weight layout is read directly
+            memset(&pk[1], 0, sizeof(PackDesc));
+            fp.p16_on = 1;
+            return 0;
+        }
+    }
     if (a.dt) {
         LineDesc &ld = fp.ld, lb;
         if (!line_geometry(a, ld) || !line_geometry(b, lb, false)) return fail("conv pair (bf16): geometry");
@@ -618,6 +696,15 @@ int plan_pair(const IgemmDesc &a, const IgemmDesc &b, bool keep_mid, Arena &ar, 
 int run_pair_f32(const PairDesc &pd, int NC, int tile, hipStream_t st);
 int run_pair(const FusedPair &fp, int NC, int tile, hipStream_t st)
 {
+    if (fp.p16_on) {
+        const Pair16Desc &q = fp.p16;
+        const long long blocks = (long long)q.a.N * q.tiles_h * q.tiles_w;
+        if (blocks == 0) return 0;
+        if (blocks >= (1LL << 31)) return fail("conv pair (16 channels): too many tiles");
+        BY_DT(fp.dt, (pair16_kernel<T><<<(unsigned)blocks, 256, 0, st>>>(q)));
+        CHECK_LAUNCH("pair16_kernel");
+        return 0;
+    }
     if (fp.dt) return run_line(fp.ld, NC, tile, true, st);
     return run_pair_f32(fp.pd, NC, tile, st);
 }
@@ -1199,6 +1286,7 @@ int erf_set_option(int option, int value)
     if (option == ERF_OPT_PAIR_FUSION) return g_sw_pair.set(value);
     if (option == ERF_OPT_WGRAD_LINE) return g_sw_wgrad_line.set(value);
     if (option == ERF_OPT_STREAM16) return g_sw_stream16.set(value);
+    if (option == ERF_OPT_PAIR16) return g_sw_pair16.set(value);
     return -1;
 }
 const char *erf_last_error(void) { return g_err; }

@@ -11,6 +11,23 @@
 #pragma once
 #include "common.h"
 
+// The 16x16x3 weights of a 16-channel convolution, staged once per block: every lane needs 12-16 of
+// them at addresses 12-192 bytes apart, and as global gathers (64 cache lines per instruction, per
+// wave) those loads cost more than the convolution's own traffic.  When the tensor is the dense
+// [16][16][3] block torch holds (checked from the strides), the block copies its 768 floats to LDS
+// with coalesced loads and the lanes pick their values there.  Returns the pointer to index with
+// woff[t] + k*wsk + j*wsn: the LDS copy, or the tensor itself.  All threads of the block must call it.
+__device__ __forceinline__ const float *stage_w16(const IgemmDesc &c, float *lds768)
+{
+    int wmax = c.woff[0] > c.woff[1] ? c.woff[0] : c.woff[1];
+    wmax = (c.woff[2] > wmax ? c.woff[2] : wmax) + 15 * (c.wsk + c.wsn);
+    const bool dense = wmax < 768 && c.wsk > 0 && c.wsn > 0 && c.woff[0] >= 0 && c.woff[1] >= 0 && c.woff[2] >= 0;
+    if (!dense) return c.w;                 // block-uniform
+    for (int e = threadIdx.x; e < 768; e += blockDim.x) lds768[e] = c.w[e];
+    __syncthreads();
+    return lds768;
+}
+
 // Forward / data gradient:  out[pix][j] = epi( sum_t sum_k in[src(pix,t)][k] * W[t][k][j] ).
 // Computed transposed, D[j][pix] = sum_k Wt[j][k] * X[k][pix], so that a lane's four D registers
 // are four consecutive channels of one pixel: loads, epilogue operands and stores are all one
@@ -26,6 +43,8 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
     const int i = lane & 15, g = lane >> 4;
     const unsigned M = (unsigned)d.N * d.GH * d.GW, GHW = (unsigned)d.GH * d.GW;
     const unsigned base0 = ((unsigned)blockIdx.x * 4 + wave) * (16 * U * G);
+    __shared__ float wlds[768];
+    const float *wsrc = stage_w16(d, wlds);
     if (base0 >= M) return;
     const unsigned Pin = (unsigned)d.N * d.in_H * d.in_W, Pout = (unsigned)d.N * d.out_H * d.out_W;
     const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, Pin * d.in_C * Act<T>::B);
@@ -39,7 +58,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const IgemmDesc d)
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wr[t][m] = d.w[d.woff[t] + (long long)(4 * g + m) * d.wsk + (long long)i * d.wsn];
+        for (int m = 0; m < 4; ++m) wr[t][m] = wsrc[d.woff[t] + (4 * g + m) * d.wsk + i * d.wsn];
 
     // Coordinates: one division pair per wave, on wave-uniform values; the tiles advance by 16
     // pixels with a uniform wrap, a lane adds its column (GW >= 16: at most one row wrap).
@@ -203,5 +222,341 @@ __global__ __launch_bounds__(NW * 64) void wgrad16_kernel(const WgradDesc d)
         else
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) P[NTAPS * 256 + t * 16 + (e - NTAPS * 256)] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two chained 16-channel 1-D convolutions in one launch (the pairs of a full-resolution
+// non_bottleneck_1d: conv1x3 -> conv3x1 and conv3x1 -> conv1x3, forward and data gradient).
+//
+//   mid = epi_a( conv_a(in) )      taps shift along one image axis
+//   out = epi_b( conv_b(mid) )     taps shift along the other
+//
+// These layers are HBM-bound, so the point is traffic and launches: the intermediate is read back
+// from LDS instead of memory (and is not written at all when the caller does not keep it).  A block
+// owns a TH x TW tile of output pixels and first forms `mid` on the tile extended by conv_b's reach
+// (`halo` pixels on both sides along conv_b's axis; <= 13 % more conv_a work, which the matrix pipe
+// has to spare), zero outside the image — conv_b's padding — then runs conv_b out of LDS.  Both
+// phases use conv16_kernel's transposed MFMA 16x16x4 formulation (a lane holds 4 consecutive channels
+// of one pixel) and its epilogue, so the results equal two conv16_kernel launches bit for bit.
+struct Pair16Desc {
+    IgemmDesc a, b;         // a.out = b.in = mid (a.out is written only with keep_mid)
+    int keep_mid;
+    int b_along_w;          // conv_b's taps shift along W (else along H)
+    int halo;               // largest |shift| of conv_b's taps (1..4)
+    int th, tw;             // tile: 8 x 64 when conv_b runs along W, 16 x 32 when it runs along H
+    int tiles_h, tiles_w;   // tiles per image
+};
+#define P16_MAX_EXT (24 * 32 > 8 * 72 ? 24 * 32 : 8 * 72)
+
+template <typename T>
+__global__ __launch_bounds__(256) void pair16_kernel(const Pair16Desc d)
+{
+    // intermediate tile in its storage type (what a separate launch would have read back)
+    __shared__ __attribute__((aligned(16))) unsigned char mids[P16_MAX_EXT * 16 * sizeof(T)];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const IgemmDesc &A = d.a, &B = d.b;
+    const int H = A.GH, W = A.GW;
+    const unsigned P = (unsigned)A.N * H * W;
+
+    int bid = (int)xcd_tile(blockIdx.x, gridDim.x);
+    const int tw_i = bid % d.tiles_w; bid /= d.tiles_w;
+    const int th_i = bid % d.tiles_h;
+    const int n = bid / d.tiles_h;
+    const int h0 = th_i * d.th, w0 = tw_i * d.tw;
+    const int hb = d.b_along_w ? 0 : d.halo, wb = d.b_along_w ? d.halo : 0;
+    const int EH = d.th + 2 * hb, EW = d.tw + 2 * wb, NE = EH * EW;
+
+    // one convolution's constants for this lane: weights (tap, k-group element m), channel affine
+    struct Side {
+        float wr[3][4];
+        f32x4 sc, sh;
+        __amdgpu_buffer_rsrc_t r_res, r_mask, r_ns;
+        bool has_res, has_mask, has_ns;
+    };
+    __shared__ float wlds[2][768];
+    auto side_init = [&](const IgemmDesc &c, Side &s, float *wl) __attribute__((always_inline)) {
+        const float *wsrc = stage_w16(c, wl);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) s.wr[t][m] = wsrc[c.woff[t] + (4 * g + m) * c.wsk + i * c.wsn];
+        const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(c.epi.bias, 64u);
+        s.sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        s.sh = buf_load4(r_bias, g * 16u);
+        if (c.epi.bn.on) {
+            const f32x4 ga = *reinterpret_cast<const f32x4 *>(c.epi.bn.gamma + 4 * g);
+            const f32x4 be = *reinterpret_cast<const f32x4 *>(c.epi.bn.beta + 4 * g);
+            const f32x4 mu = *reinterpret_cast<const f32x4 *>(c.epi.bn.mean + 4 * g);
+            const f32x4 va = *reinterpret_cast<const f32x4 *>(c.epi.bn.var + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float inv = c.epi.bn.var_is_invstd ? va[r] : rsqrtf(va[r] + c.epi.bn.eps);
+                s.sc[r] = ga[r] * inv;
+                s.sh[r] = (s.sh[r] - mu[r]) * s.sc[r] + be[r];
+            }
+        }
+        s.r_res = make_rsrc(c.epi.res, P * c.epi.res_C * Act<T>::B);
+        s.r_mask = make_rsrc(c.epi.mask, P * c.epi.mask_C * Act<T>::B);
+        s.r_ns = make_rsrc(c.epi.nscale, (unsigned)c.N * 64u);
+        s.has_res = c.epi.res != nullptr; s.has_mask = c.epi.mask != nullptr; s.has_ns = c.epi.nscale != nullptr;
+    };
+    // conv16_kernel's epilogue for the lane's 4 channels of pixel px (the optional operands were
+    // loaded by the caller, ahead of the MFMAs)
+    auto finish = [&](const IgemmDesc &c, const Side &s, f32x4 acc, f32x4 rres, f32x4 rmask, f32x4 rns) __attribute__((always_inline)) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float e = acc[r] * s.sc[r] + s.sh[r];
+            if (s.has_ns) e *= rns[r];
+            e += rres[r];
+            if (c.epi.relu) e = fmaxf(e, 0.0f);
+            v[r] = rmask[r] > 0.0f ? e : 0.0f;
+        }
+        return v;
+    };
+    auto load_opt = [&](const IgemmDesc &c, const Side &s, unsigned px, unsigned bad, f32x4 &rres, f32x4 &rmask, f32x4 &rns) __attribute__((always_inline)) {
+        rres = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        rmask = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        rns = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+        if (s.has_res) rres = Act<T>::load4(s.r_res, (px * c.epi.res_C + c.epi.res_coff + 4 * g) | bad);
+        if (s.has_mask) rmask = Act<T>::load4(s.r_mask, (px * c.epi.mask_C + c.epi.mask_coff + 4 * g) | bad);
+        if (s.has_ns) rns = buf_load4(s.r_ns, ((unsigned)n * 16 + 4 * g) * 4u);
+    };
+
+    Side SA, SB;            // both convolutions' constants up front: one exposed latency
+    side_init(A, SA, wlds[0]);
+    side_init(B, SB, wlds[1]);
+    // ------------------------------------------------------------------ phase 1: mid on the extended tile
+    {
+        const Side &S = SA;
+        const __amdgpu_buffer_rsrc_t r_in = make_rsrc(A.in, P * A.in_C * Act<T>::B);
+        constexpr int U = 4;
+        const int ngroups = (NE + 15) / 16;
+        for (int g0 = wave * U; g0 < ngroups; g0 += 4 * U) {
+            f32x4 xv[U][3], rres[U], rmask[U], rns[U];
+            int eidx[U];
+            unsigned opx[U];
+            bool inimg[U], interior[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = (g0 + u) * 16 + i;
+                const bool live = e < NE;
+                const int r = e / EW, c = e - r * EW;
+                const int ih = h0 - hb + r, iw = w0 - wb + c;
+                inimg[u] = live && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+                interior[u] = inimg[u] && r >= hb && r < hb + d.th && c >= wb && c < wb + d.tw;
+                eidx[u] = live ? e : -1;
+                const unsigned px = ((unsigned)n * H + ih) * W + iw;
+                opx[u] = px;
+                const unsigned vbad = inimg[u] ? 0u : ERF_OOB;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int sh_ = ih + A.tdh[t], sw_ = iw + A.tdw[t];
+                    const unsigned bad = (unsigned)((sh_ | sw_ | (H - 1 - sh_) | (W - 1 - sw_)) >> 31) & ERF_OOB;
+                    const unsigned off = (((unsigned)n * H + sh_) * W + sw_) * A.in_C + A.in_coff + 4 * g;
+                    xv[u][t] = Act<T>::load4(r_in, off | bad | vbad);
+                }
+                load_opt(A, S, px, vbad, rres[u], rmask[u], rns[u]);
+            }
+            f32x4 acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.wr[t][m], xv[u][t][m], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (eidx[u] < 0) continue;
+                f32x4 v = finish(A, S, acc[u], rres[u], rmask[u], rns[u]);
+                if (!inimg[u]) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};       // conv_b's zero padding
+                Act<T>::st4(mids, (long long)eidx[u] * 16 + 4 * g, v);
+                if (d.keep_mid && interior[u]) Act<T>::st4(A.out, (long long)(opx[u] * A.out_C + A.out_coff + 4 * g), v);
+            }
+        }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ phase 2: conv_b out of LDS
+    {
+        const Side &S = SB;
+        constexpr int U = 4;
+        const int NO = d.th * d.tw, ngroups = NO / 16;
+        int esh[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) esh[t] = B.tdh[t] * EW + B.tdw[t];       // tap shift in extended-tile positions
+        for (int g0 = wave * U; g0 < ngroups; g0 += 4 * U) {
+            f32x4 xv[U][3], rres[U], rmask[U], rns[U];
+            unsigned opx[U];
+            bool valid[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int o = (g0 + u) * 16 + i;
+                const bool live = g0 + u < ngroups;
+                const int r = o / d.tw, c = o - r * d.tw;
+                const int oh = h0 + r, ow = w0 + c;
+                valid[u] = live && oh < H && ow < W;
+                const int e = live ? (r + hb) * EW + c + wb : (hb * EW + wb);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) xv[u][t] = Act<T>::ld4(mids, (long long)(e + esh[t]) * 16 + 4 * g);
+                const unsigned px = ((unsigned)n * H + oh) * W + ow;
+                opx[u] = px;
+                load_opt(B, S, px, valid[u] ? 0u : ERF_OOB, rres[u], rmask[u], rns[u]);
+            }
+            f32x4 acc[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(S.wr[t][m], xv[u][t][m], acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!valid[u]) continue;
+                const f32x4 v = finish(B, S, acc[u], rres[u], rmask[u], rns[u]);
+                Act<T>::st4(B.out, (long long)(opx[u] * B.out_C + B.out_coff + 4 * g), v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv16_kernel for bf16 tensors on v_mfma_f32_16x16x32_bf16: at 16 channels the fp32-MFMA kernel
+// above is bound by instruction issue, not by memory (48 MFMAs of 32 cycles and about 200 address /
+// conversion instructions per 64 pixels: four plain copies of the tensor take a fifth of the time of
+// four convolutions).  Here the bf16 data goes from memory into the MFMA operand as it is:
+//   D[j][pixel] = sum_k Wt[j][k] X[k][pixel],  k = 32 = two taps x 16 input channels per instruction
+// so a tile of 16 pixels takes two 16-byte loads per lane and two MFMAs of 16 cycles (taps 0+1, then
+// tap 2 with the upper half of k zero) instead of three 8-byte loads, twelve unpackings and twelve
+// MFMAs.  Lane (i, g) = (lane & 15, lane >> 4) supplies pixel i, k = 8g..8g+7: tap g >> 1, channels
+// 8 (g & 1) .. +7; it receives channels 4g..4g+3 of pixel i, as in conv16_kernel, so the epilogue and
+// the store are the same.  U independent tiles per batch, G batches per wave.
+template <int U, int G>
+__global__ __launch_bounds__(256) void conv16_bf16_kernel(const IgemmDesc d)
+{
+    typedef bf16_t T;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned M = (unsigned)d.N * d.GH * d.GW, GHW = (unsigned)d.GH * d.GW;
+    const unsigned base0 = ((unsigned)blockIdx.x * 4 + wave) * (16 * U * G);
+    __shared__ float wlds[768];
+    const float *wsrc = stage_w16(d, wlds);
+    if (base0 >= M) return;
+    const unsigned Pin = (unsigned)d.N * d.in_H * d.in_W, Pout = (unsigned)d.N * d.out_H * d.out_W;
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, Pin * d.in_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, (unsigned)d.N * 64u);
+    const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
+    const bool has_ns = d.epi.nscale != nullptr, has_mask = d.epi.mask != nullptr, has_res = d.epi.res != nullptr;
+
+    // weight operands: lane (j = i, g) holds Wt[j][k = 8g..8g+7]; second instruction: tap 2, upper k zero
+    bf16x8 wa, wb;
+    {
+        const int t = g >> 1, c0 = 8 * (g & 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wa[e] = (__bf16)wsrc[d.woff[t] + (c0 + e) * d.wsk + i * d.wsn];
+            const float w2 = wsrc[d.woff[2] + (c0 + e) * d.wsk + i * d.wsn];
+            wb[e] = (__bf16)(g < 2 ? w2 : 0.0f);
+        }
+    }
+    // this lane's tap shifts: first load tap g >> 1, second load tap 2 (lanes g >= 2 load nothing)
+    const int dh1 = d.tdh[g >> 1], dw1 = d.tdw[g >> 1], dh2 = d.tdh[2], dw2 = d.tdw[2];
+    const unsigned c8 = (unsigned)d.in_coff + 8u * (g & 1);
+    const unsigned upper = g >= 2 ? ERF_OOB : 0u;
+
+    unsigned tn = base0 / GHW;
+    unsigned trem = base0 - tn * GHW;
+    unsigned tgi = trem / (unsigned)d.GW, tgj = trem - tgi * d.GW;
+    f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    f32x4 sh = buf_load4(r_bias, g * 16u);
+    if (d.epi.bn.on) {          // wave-uniform
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(d.epi.bn.gamma + 4 * g);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(d.epi.bn.beta + 4 * g);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(d.epi.bn.mean + 4 * g);
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(d.epi.bn.var + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = d.epi.bn.var_is_invstd ? va[r] : rsqrtf(va[r] + d.epi.bn.eps);
+            sc[r] = ga[r] * inv;
+            sh[r] = (sh[r] - mu[r]) * sc[r] + be[r];
+        }
+    }
+
+    for (int grp = 0; grp < G; ++grp) {
+        const unsigned base = base0 + grp * (16 * U);
+        if (base >= M) break;
+        u32x4 x1[U], x2[U];
+        f32x4 rres[U], rmask[U], rns[U];
+        int opix[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned m = base + u * 16 + i;
+            const bool valid = m < M;
+            unsigned n = tn, gi = tgi, gj = tgj + i;
+            if (gj >= (unsigned)d.GW) {
+                gj -= d.GW;
+                gi += 1;
+                if (gi == (unsigned)d.GH) { gi = 0; n += 1; }
+            }
+            const unsigned px = (n * d.out_H + gi) * d.out_W + gj;
+            opix[u] = valid ? (int)px : -1;
+            const unsigned vbad = valid ? 0u : ERF_OOB;
+            {
+                const int ih = (int)gi + dh1, iw = (int)gj + dw1;
+                const unsigned bad = (unsigned)((ih | iw | (d.in_H - 1 - ih) | (d.in_W - 1 - iw)) >> 31) & ERF_OOB;
+                const unsigned off = (((n * d.in_H + ih) * d.in_W + iw) * d.in_C + c8) * 2u;
+                x1[u] = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)(off | bad | vbad), 0, 0);
+            }
+            {
+                const int ih = (int)gi + dh2, iw = (int)gj + dw2;
+                const unsigned bad = (unsigned)((ih | iw | (d.in_H - 1 - ih) | (d.in_W - 1 - iw)) >> 31) & ERF_OOB;
+                const unsigned off = (((n * d.in_H + ih) * d.in_W + iw) * d.in_C + c8) * 2u;
+                x2[u] = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)(off | bad | vbad | upper), 0, 0);
+            }
+            rres[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            rmask[u] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+            rns[u] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+            if (has_res) rres[u] = Act<T>::load4(r_res, (px * d.epi.res_C + d.epi.res_coff + 4 * g) | vbad);
+            if (has_mask) rmask[u] = Act<T>::load4(r_mask, (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) | vbad);
+            if (has_ns) rns[u] = buf_load4(r_ns, (n * 16 + 4 * g) * 4u);
+            tgj += 16;                                   // uniform advance to the next tile
+            while (tgj >= (unsigned)d.GW) {
+                tgj -= d.GW;
+                if (++tgi == (unsigned)d.GH) { tgi = 0; ++tn; }
+            }
+        }
+        f32x4 acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1[u]), f32x4{0.0f, 0.0f, 0.0f, 0.0f}, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, __builtin_bit_cast(bf16x8, x2[u]), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = acc[u][r] * sc[r] + sh[r];
+                if (has_ns) e *= rns[u][r];
+                e += rres[u][r];
+                if (d.epi.relu) e = fmaxf(e, 0.0f);
+                v[r] = rmask[u][r] > 0.0f ? e : 0.0f;
+            }
+            if (opix[u] >= 0)
+                Act<T>::st4(d.out, (long long)((unsigned)opix[u] * d.out_C + d.out_coff + 4 * g), v);
+        }
     }
 }

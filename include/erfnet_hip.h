@@ -63,6 +63,9 @@ unsigned long long erf_launch_count(void);
  * implicit-GEMM kernels.  Either way the results agree to fp32 rounding (different summation order). */
 #define ERF_OPT_WGRAD_LINE 2
 #define ERF_OPT_STREAM16 3
+/* ERF_OPT_PAIR16 (default 0; ERFNET_PAIR16=1): the conv pairs of the 16-channel blocks as one launch
+ * (pair16_kernel) under ERF_OPT_PAIR_FUSION; same results, currently slower than two launches. */
+#define ERF_OPT_PAIR16 4
 int erf_set_option(int option, int value);
 
 /* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block

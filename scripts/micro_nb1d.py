@@ -9,16 +9,20 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--c", type=int, default=128); ap.add_argument("--h", type=int, default=64)
 ap.add_argument("--w", type=int, default=128); ap.add_argument("--n", type=int, default=6)
 ap.add_argument("--d", type=int, default=2); ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--bwd", action="store_true")
+ap.add_argument("--bwd", action="store_true"); ap.add_argument("--bf16", action="store_true"); ap.add_argument("--copy", action="store_true")
 a = ap.parse_args()
 dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
 x = torch.randn(a.n, a.c, a.h, a.w, generator=g).clamp_(min=0).to(dev).contiguous(memory_format=torch.channels_last)
+if a.bf16: x = x.to(torch.bfloat16)
 ws = [(torch.randn(a.c, a.c, *k, generator=g) * 0.05).to(dev).requires_grad_(a.bwd) for k in ((3, 1), (1, 3), (3, 1), (1, 3))]
 bs = [torch.zeros(a.c, device=dev).requires_grad_(a.bwd) for _ in range(4)]
-gy = torch.randn(a.n, a.c, a.h, a.w, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+gy = torch.randn(a.n, a.c, a.h, a.w, generator=g).to(dev).contiguous(memory_format=torch.channels_last).to(x.dtype)
+ybuf = torch.empty_like(x)
 def run():
-    if a.bwd:
+    if a.copy:          # reference point: four plain device copies of the same tensor
+        for _ in range(4): ybuf.copy_(x)
+    elif a.bwd:
         xx = x.clone().requires_grad_(True)
         y = hipf.nb1d(xx, ws, bs, a.d); y.backward(gy)
     else:

@@ -617,10 +617,12 @@ def test_graphed_forward_replays_the_eager_result():
 
 @pytest.mark.parametrize("C_,d,N,H,W", [(128, 2, 2, 40, 24), (128, 16, 1, 64, 20), (64, 1, 2, 72, 20),
                                         (64, 2, 1, 128, 12), (128, 8, 3, 28, 28), (64, 1, 2, 56, 56),
-                                        (128, 1, 1, 17, 33)])
+                                        (128, 1, 1, 17, 33), (16, 1, 2, 40, 48), (16, 1, 1, 17, 33),
+                                        (16, 2, 1, 24, 100), (16, 4, 1, 33, 70)])
 @pytest.mark.parametrize("bn_mode", [0, 1, 2])
 def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
-    """Two chained 1-D convolutions in one launch (pair_f32_kernel, image columns as block tiles)
+    """Two chained 1-D convolutions in one launch (pair_f32_kernel, image columns as block tiles;
+    pair16_kernel, 2-D tiles with a halo, at 16 channels)
     must reproduce the one-launch-per-convolution path bit for bit: inference output, training
     output, input gradient and every parameter gradient, with and without BatchNorm."""
     from erfnet_pytorch_amd import functional as hipf, _lib
@@ -652,6 +654,7 @@ def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
 
     res = {}
     prev = _lib.set_option(_lib.OPT_PAIR_FUSION, 1)
+    prev16 = _lib.set_option(_lib.OPT_PAIR16, 1)        # (off by default: not faster yet)
     try:
         for on in (0, 1):
             _lib.set_option(_lib.OPT_PAIR_FUSION, on)
@@ -659,6 +662,7 @@ def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
             res[on] = (a + b, n1 - n0, n2 - n1)
     finally:
         _lib.set_option(_lib.OPT_PAIR_FUSION, prev)
+        _lib.set_option(_lib.OPT_PAIR16, prev16)
     # without BatchNorm the forward pair and both backward pairs fuse; inference folds eval-mode
     # BatchNorm into the epilogue (pair possible); batch statistics, or a BatchNorm whose input is
     # kept for backward, sit between the two convolutions of the forward pair, never between those
