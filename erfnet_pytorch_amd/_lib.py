@@ -127,7 +127,7 @@ _PROTOS["erf_outconv_forward_bf16"] = (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_in
                                                  C.c_int, C.c_int, vp])
 
 BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
-OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16, OPT_PAIR16 = 1, 2, 3, 4
+OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16, OPT_PAIR16, OPT_LINE2 = 1, 2, 3, 4, 5
 
 EXPORTS = tuple(_PROTOS)
 

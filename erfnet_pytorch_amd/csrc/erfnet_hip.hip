@@ -7,6 +7,7 @@
 #include "sampler16.h"
 #include "pair.h"
 #include "line_bf16.h"
+#include "line2_bf16.h"
 #include "igemm_bf16.h"
 #include "wgrad_line.h"
 #include "wgrad_line_bf16.h"
@@ -54,6 +55,7 @@ Switch g_sw_pair("ERFNET_NO_PAIR"), g_sw_wgrad_line("ERFNET_NO_WGRAD_LINE"), g_s
 // off by default: measured 5-12 % slower than two conv16_kernel launches (both are issue-bound, not
 // memory-bound, at 16 channels); ERFNET_PAIR16=1 or ERF_OPT_PAIR16 turns it on
 Switch g_sw_pair16("ERFNET_PAIR16", 0);
+std::atomic<int> g_line2{1};        // ERF_OPT_LINE2
 
 int fail(const char *fmt, ...)
 {
@@ -181,6 +183,20 @@ int run_line(const LineDesc &ld, int NC, int BM, bool pair, hipStream_t st)
     if (ntiles <= 0) return 0;
     const int cus = cu_count();
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+    // Pairs whose blocks see at least two tiles take the eight-wave kernel (conv_a of tile k+1 beside
+    // conv_b of tile k); ERFNET_NO_LINE2=1 keeps them on the four-wave one (experiments, A/B tests).
+    static int no_line2 = -1;
+    if (no_line2 < 0) { const char *e = getenv("ERFNET_NO_LINE2"); no_line2 = (e && atoi(e)) ? 1 : 0; }
+    if (pair && !no_line2 && g_line2.load(std::memory_order_relaxed) && ld.segs == 1 && ntiles >= 2 * (int)grid) {
+#define LINE2_CASE(nc, bm)                                                                          \
+        if (NC == nc && BM == bm) {                                                                 \
+            line2_bf16_kernel<nc, bm><<<grid, 512, 0, st>>>(ld);                                    \
+            CHECK_LAUNCH("line2_bf16_kernel");                                                      \
+            return 0;                                                                               \
+        }
+        LINE2_CASE(128, 32) LINE2_CASE(128, 64) LINE2_CASE(64, 64) LINE2_CASE(64, 128)
+#undef LINE2_CASE
+    }
 #define LINE_CASE(nc, bm)                                                                           \
     if (NC == nc && BM == bm) {                                                                     \
         if (pair) line_bf16_kernel<nc, bm, true><<<grid, 256, 0, st>>>(ld);                        \
@@ -1287,6 +1303,7 @@ int erf_set_option(int option, int value)
     if (option == ERF_OPT_WGRAD_LINE) return g_sw_wgrad_line.set(value);
     if (option == ERF_OPT_STREAM16) return g_sw_stream16.set(value);
     if (option == ERF_OPT_PAIR16) return g_sw_pair16.set(value);
+    if (option == ERF_OPT_LINE2) return g_line2.exchange(value ? 1 : 0);
     return -1;
 }
 const char *erf_last_error(void) { return g_err; }

@@ -1,0 +1,331 @@
+// The fused pair of line_bf16_kernel with TWO waves per SIMD, specialised by convolution.
+//
+// line_bf16_kernel keeps the weights of both convolutions in every wave's registers, which leaves
+// room for one wave per SIMD: the DMA waits, the LDS fragment reads and both epilogues of a tile run
+// with nothing to overlap them (measured: 11.8 k cycles per 64-row tile of 128 channels against 3.1 k
+// of MFMA issue).  Here a block has eight waves:
+//   waves 0-3 ("A") hold w1 and run conv_a of tile k+1 (DMA'd operand tiles, first epilogue into the
+//                   intermediate tile MID[(k+1) & 1], optional store / mask pass of the intermediate),
+//   waves 4-7 ("B") hold w2 and run conv_b of tile k out of MID[k & 1], the final epilogue and the
+//                   output pass,
+// so each SIMD hosts one A wave and one B wave whose MFMAs fill each other's waits.  The arithmetic of
+// a tile is line_bf16_kernel's, instruction for instruction: results are bit-identical (tested).
+//
+// Synchronisation: s_barrier joins all eight waves, so both roles execute the SAME number of
+// barriers per period — five, whatever the tile's geometry — and the same number of periods (A: its
+// K tiles + one drain period; B: one idle period + its K tiles):
+//            A (tile k+1)                                   B (tile k)
+//   X1   tap 0 landed                                 residual tile landed, conv_b MFMAs issued
+//   X2   tap 1 landed                                 accumulators (+ residual) stored to the RES tile
+//   X3   tap 2 landed                                 output pass has read the RES tile
+//   X4   intermediate stored to MID                   -
+//   X5   intermediate's store / mask pass done        -            (B may read MID[(k+1) & 1] after X5)
+// A writes MID[(k+1) & 1] behind X3 of its period; B read that buffer (tile k-1) before X1 of the
+// period before: no further hand-shake is needed.
+#pragma once
+#include "line_bf16.h"
+
+template <int NC, int BM>
+__global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
+{
+    constexpr int GC = NC / 32, GP = 4 / GC, WM = BM / (32 * GP);
+    static_assert(WM >= 1 && WM * GP * 32 == BM, "tile shape");
+    constexpr int KS = NC / 16;
+    constexpr int CPR = NC / 8;
+    constexpr int PITCH = NC * 2;
+    constexpr int T = BM * PITCH;
+    constexpr int PASSES = BM * CPR / 256;
+    static_assert(BM * CPR % 256 == 0, "whole copy passes");
+    constexpr int MIDSZ = T + PITCH;                        // tile + zero row
+    constexpr int OFF_TAP = 0, OFF_MID = 2 * T, OFF_RES = OFF_MID + 2 * MIDSZ, OFF_RESA = OFF_RES + T;
+    constexpr int OFF_CST = OFF_RESA + T;
+    static_assert(OFF_CST + 4 * NC * 4 <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_CST + 4 * NC * 4];
+    float *cst = reinterpret_cast<float *>(lds + OFF_CST);        // sc1[NC] sh1[NC] sc2[NC] sh2[NC]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool role_a = wave8 < 4;                          // wave-uniform
+    const int wave = wave8 & 3, ltid = tid & 255;           // index within the role
+    const int cg = wave % GC, wp = wave / GC;
+    const int l31 = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
+
+    const int L = d.L;
+    const int ntiles = d.nlines;                            // a pair covers whole lines (segs = 1)
+    const int nblk = gridDim.x;
+    const int b0 = (int)xcd_tile(blockIdx.x, nblk);
+    const int s1a = d.s1[0], s1b = d.s1[1], s1c = d.s1[2];
+    const bool res_first = d.epi1.res != nullptr;
+    const bool res_last = d.epi2.res != nullptr;
+    const int K = b0 < ntiles ? (ntiles - b0 + nblk - 1) / nblk : 0;      // tiles of this block
+
+    struct Geo { int q; unsigned base; int len; };
+    auto geo = [&](int tile) __attribute__((always_inline)) {
+        Geo g;
+        const int n = tile / d.lines_per_img;
+        g.q = tile - n * d.lines_per_img;
+        g.len = L < BM ? L : BM;
+        g.base = (unsigned)n * d.img_pixels + (unsigned)g.q * d.qstride;
+        return g;
+    };
+    auto tap_shift = [&](int t) __attribute__((always_inline)) { return t == 0 ? s1a : (t == 1 ? s1b : s1c); };
+    auto tap_valid = [&](const Geo &g, int t) __attribute__((always_inline)) {
+        return (unsigned)(g.q + tap_shift(t)) < (unsigned)d.lines_per_img;
+    };
+    // LDS-DMA of one line tile by the 256 threads of a role
+    auto issue_tile = [&](const bf16_t *src, unsigned pixel0, int len, int dst_off) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int slot = p * 256 + ltid;
+            const int r = slot / CPR, pc = slot % CPR;
+            const int c = pc ^ line_swz<NC>(r);
+            const int rr = r < len ? r : len - 1;
+            const bf16_t *gp = src + ((size_t)(pixel0 + (unsigned)(rr * d.pstride)) * NC + c * 8);
+            lds_dma16(gp, lds0 + dst_off + (p * 256 + wave * 64) * 16);
+        }
+    };
+
+    // common set-up: epilogue constants, zero rows of both MID buffers
+    for (int c = tid; c < NC; c += 512) {
+        float sc, sh;
+        epi_channel_affine(d.epi1, c, sc, sh);
+        cst[c] = sc; cst[NC + c] = sh;
+        epi_channel_affine(d.epi2, c, sc, sh);
+        cst[2 * NC + c] = sc; cst[3 * NC + c] = sh;
+    }
+    for (int i = tid; i < 2 * (PITCH / 4); i += 512) {
+        const int buf = i / (PITCH / 4), e = i % (PITCH / 4);
+        reinterpret_cast<unsigned *>(lds + OFF_MID + buf * MIDSZ + T)[e] = 0u;
+    }
+
+    f32x16 acc[WM];
+    auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    };
+    auto mma_tap = [&](const bf16x8 (&w)[KS], const unsigned char *const (&rowp)[WM], const unsigned (&x4)[WM]) __attribute__((always_inline)) {
+        constexpr int D = WM >= 4 ? 2 : 3;
+        bf16x8 xf[D][WM];
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s)
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+                xf[s][a] = *reinterpret_cast<const bf16x8 *>(rowp[a] + ((unsigned)(s << 5) ^ x4[a]));
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + D - 1 < KS) {
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+                    xf[(s + D - 1) % D][a] = *reinterpret_cast<const bf16x8 *>(rowp[a] + ((unsigned)((s + D - 1) << 5) ^ x4[a]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < WM; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], xf[s % D][a], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // coalesced pass of a role over a finished LDS tile: [mask by a global tensor, kept in the tile] -> [global store]
+    auto sweep_tile = [&](int lds_off, const bf16_t *mk, bf16_t *dst, bool keep, const Geo &g) __attribute__((always_inline)) {
+        constexpr int B = PASSES % 4 == 0 ? 4 : (PASSES % 2 == 0 ? 2 : 1);
+#pragma unroll
+        for (int p0 = 0; p0 < PASSES; p0 += B) {
+            u32x4 v[B], m[B];
+            size_t off[B];
+            bool live[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                const int slot = (p0 + i) * 256 + ltid;
+                const int r = slot / CPR, pc = slot % CPR;
+                const int c = pc ^ line_swz<NC>(r);
+                live[i] = r < g.len;
+                const int rr = live[i] ? r : g.len - 1;
+                off[i] = (size_t)(g.base + (unsigned)(rr * d.pstride)) * NC + c * 8;
+                v[i] = *reinterpret_cast<const u32x4 *>(lds + lds_off + slot * 16);
+            }
+            if (mk) {
+#pragma unroll
+                for (int i = 0; i < B; ++i) m[i] = *reinterpret_cast<const u32x4 *>(mk + off[i]);
+#pragma unroll
+                for (int i = 0; i < B; ++i) v[i] = mask_bf16x8(v[i], m[i]);
+                if (keep) {
+#pragma unroll
+                    for (int i = 0; i < B; ++i) *reinterpret_cast<u32x4 *>(lds + lds_off + ((p0 + i) * 256 + ltid) * 16) = v[i];
+                }
+            }
+            if (dst) {
+#pragma unroll
+                for (int i = 0; i < B; ++i)
+                    if (live[i]) *reinterpret_cast<u32x4 *>(dst + off[i]) = v[i];
+            }
+        }
+    };
+    auto store_acc_t = [&](auto relu_t, auto scale_t, auto res_t, const float *sc_, const float *sh_, bool zero_dead,
+                           int res_off, int dst_off, const Geo &g) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(relu_t)::value, SCALE = decltype(scale_t)::value, RES = decltype(res_t)::value;
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const bool ragged = zero_dead && g.len < BM;
+        f32x4 sc[4], sh[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch = 32 * cg + 8 * gq + 4 * h;
+            if (SCALE) sc[gq] = *reinterpret_cast<const f32x4 *>(sc_ + ch);
+            sh[gq] = *reinterpret_cast<const f32x4 *>(sh_ + ch);
+        }
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+            const int px = (wp * WM + a) * 32 + l31;
+            const int sw = line_swz<NC>(px);
+            u32x2 rr[4];
+            if (RES) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    rr[gq] = *reinterpret_cast<const u32x2 *>(lds + res_off + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h);
+            }
+            u32x2 pk[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 v = f32x4{acc[a][4 * gq], acc[a][4 * gq + 1], acc[a][4 * gq + 2], acc[a][4 * gq + 3]};
+                if (SCALE) v = v * sc[gq] + sh[gq];
+                else v = v + sh[gq];
+                if (RES) v = v + unpack_bf16x4(rr[gq]);
+                pk[gq] = pack_bf16x4(v);
+                if (RELU) pk[gq] = __builtin_bit_cast(u32x2, __builtin_elementwise_max(__builtin_bit_cast(s16x4, pk[gq]), s16x4{0, 0, 0, 0}));
+            }
+            if (ragged) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) pk[gq] = px < g.len ? pk[gq] : u32x2{0u, 0u};
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<u32x2 *>(lds + dst_off + px * PITCH + (((4 * cg + gq) ^ sw) << 4) + 8 * h) = pk[gq];
+        }
+    };
+    auto store_acc = [&](const Epilogue &e, const float *sc_, const float *sh_, bool add_res, bool zero_dead,
+                         int res_off, int dst_off, const Geo &g) __attribute__((always_inline)) {
+        using T1 = std::true_type;
+        using T0 = std::false_type;
+        const int key = (e.relu ? 4 : 0) | (e.bn.on ? 2 : 0) | (add_res ? 1 : 0);
+        switch (key) {          // wave-uniform
+        case 0: store_acc_t(T0{}, T0{}, T0{}, sc_, sh_, zero_dead, res_off, dst_off, g); break;
+        case 1: store_acc_t(T0{}, T0{}, T1{}, sc_, sh_, zero_dead, res_off, dst_off, g); break;
+        case 2: store_acc_t(T0{}, T1{}, T0{}, sc_, sh_, zero_dead, res_off, dst_off, g); break;
+        case 3: store_acc_t(T0{}, T1{}, T1{}, sc_, sh_, zero_dead, res_off, dst_off, g); break;
+        case 4: store_acc_t(T1{}, T0{}, T0{}, sc_, sh_, zero_dead, res_off, dst_off, g); break;
+        case 5: store_acc_t(T1{}, T0{}, T1{}, sc_, sh_, zero_dead, res_off, dst_off, g); break;
+        case 6: store_acc_t(T1{}, T1{}, T0{}, sc_, sh_, zero_dead, res_off, dst_off, g); break;
+        default: store_acc_t(T1{}, T1{}, T1{}, sc_, sh_, zero_dead, res_off, dst_off, g); break;
+        }
+    };
+
+    if (K == 0) return;             // (block-uniform: no barrier has been executed yet)
+    clear_acc();
+    if (role_a) {
+        // ================================================================= role A: conv_a, tile by tile
+        bf16x8 w1[3][KS];
+        int seq = 0;
+        Geo g = geo(b0);
+        {
+            int t = 0;
+            while (!tap_valid(g, t)) ++t;
+            issue_tile(d.in, g.base + (unsigned)(tap_shift(t) * d.qstride), g.len, OFF_TAP);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                w1[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8);
+        __syncthreads();            // set-up (constants, zero rows) visible; B executes the same barrier
+        for (int k = 0; k < K; ++k) {
+            const bool more = k + 1 < K;
+            Geo gn = g;
+            if (more) gn = geo(b0 + (k + 1) * nblk);
+            if (res_first) issue_tile((const bf16_t *)d.epi1.res, g.base, g.len, OFF_RESA);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bool tv = tap_valid(g, t);            // wave-uniform
+                if (tv) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();                              // X1..X3
+                if (!tv) continue;
+                int nt = t + 1;
+                while (nt < 3 && !tap_valid(g, nt)) ++nt;
+                if (nt < 3) {
+                    issue_tile(d.in, g.base + (unsigned)(tap_shift(nt) * d.qstride), g.len, OFF_TAP + ((seq + 1) & 1) * T);
+                } else if (more) {
+                    int ft = 0;
+                    while (!tap_valid(gn, ft)) ++ft;
+                    issue_tile(d.in, gn.base + (unsigned)(tap_shift(ft) * d.qstride), gn.len, OFF_TAP + ((seq + 1) & 1) * T);
+                }
+                const unsigned char *tb = lds + OFF_TAP + (seq & 1) * T;
+                const unsigned char *rowp[WM];
+                unsigned x4[WM];
+#pragma unroll
+                for (int a = 0; a < WM; ++a) {
+                    const int px = (wp * WM + a) * 32 + l31;
+                    rowp[a] = tb + px * PITCH;
+                    x4[a] = (unsigned)((line_swz<NC>(px) ^ h) << 4);
+                }
+                mma_tap(w1[t], rowp, x4);
+                ++seq;
+            }
+            const int mid_off = OFF_MID + (k & 1) * MIDSZ;
+            store_acc(d.epi1, cst, cst + NC, res_first, true, OFF_RESA, mid_off, g);
+            clear_acc();
+            lds_barrier();                                  // X4
+            const bf16_t *mk1 = (const bf16_t *)d.epi1.mask;
+            if (d.mid || mk1) sweep_tile(mid_off, mk1, d.mid, true, g);
+            lds_barrier();                                  // X5
+            g = gn;
+        }
+        // drain period: B works on the last tile
+#pragma unroll
+        for (int x = 0; x < 5; ++x) lds_barrier();
+    } else {
+        // ================================================================= role B: conv_b + output, one tile behind
+        bf16x8 w2[3][KS];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                w2[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp2 + ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8);
+        __syncthreads();            // (pairs with A's set-up barrier)
+        Geo g = geo(b0);
+        if (res_last) issue_tile((const bf16_t *)d.epi2.res, g.base, g.len, OFF_RES);
+        // idle period: A works on the first tile
+#pragma unroll
+        for (int x = 0; x < 5; ++x) lds_barrier();
+        for (int k = 0; k < K; ++k) {
+            const bool more = k + 1 < K;
+            Geo gn = g;
+            if (more) gn = geo(b0 + (k + 1) * nblk);
+            const int mid_off = OFF_MID + (k & 1) * MIDSZ;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int sft = d.s2[t];
+                const unsigned char *rowp[WM];
+                unsigned x4[WM];
+#pragma unroll
+                for (int a = 0; a < WM; ++a) {
+                    const int rr = (wp * WM + a) * 32 + l31 + sft;
+                    const int rz = (unsigned)rr < (unsigned)g.len ? rr : BM;        // beyond the line: the zero row
+                    rowp[a] = lds + mid_off + rz * PITCH;
+                    x4[a] = (unsigned)((line_swz<NC>(rz) ^ h) << 4);
+                }
+                mma_tap(w2[t], rowp, x4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the residual tile has landed (this wave's part)
+            lds_barrier();                                  // X1
+            store_acc(d.epi2, cst + 2 * NC, cst + 3 * NC, res_last, false, OFF_RES, OFF_RES, g);
+            clear_acc();
+            lds_barrier();                                  // X2
+            sweep_tile(OFF_RES, (const bf16_t *)d.epi2.mask, d.out, false, g);
+            lds_barrier();                                  // X3: the RES tile may be refilled
+            if (more && res_last) issue_tile((const bf16_t *)d.epi2.res, gn.base, gn.len, OFF_RES);
+            lds_barrier();                                  // X4
+            lds_barrier();                                  // X5
+            g = gn;
+        }
+    }
+}

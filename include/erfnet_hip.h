@@ -66,6 +66,9 @@ unsigned long long erf_launch_count(void);
 /* ERF_OPT_PAIR16 (default 0; ERFNET_PAIR16=1): the conv pairs of the 16-channel blocks as one launch
  * (pair16_kernel) under ERF_OPT_PAIR_FUSION; same results, currently slower than two launches. */
 #define ERF_OPT_PAIR16 4
+/* ERF_OPT_LINE2 (default 1; ERFNET_NO_LINE2=1): bf16 conv pairs on the eight-wave kernel whose wave
+ * groups work on consecutive tiles (line2_bf16_kernel); off = the four-wave kernel; same results. */
+#define ERF_OPT_LINE2 5
 int erf_set_option(int option, int value);
 
 /* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block

@@ -328,3 +328,89 @@ def test_fullres_1024x2048_erfnet_nobn_bf16():
     ok = extra["fullres/margin_s2"].astype(np.float32) > 2e-2 * scale
     assert ok.mean() > 0.3
     assert np.array_equal(y.argmax(1)[:, ::2, ::2].astype(np.uint8)[ok], extra["fullres/argmax_s2"][ok])
+
+
+def _pair_bf16(n, c, h, w, axis, d1, d2, keep_mid, res, seed):
+    """erf_conv_pair_forward_bf16 on seeded tensors -> (mid or None, y) as int16 bit patterns."""
+    import ctypes as C
+    from erfnet_pytorch_amd import _lib
+    lib = _lib.lib()
+    p = lambda t_: None if t_ is None else C.c_void_p(t_.data_ptr())
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g).clamp_(min=0).to(DEV).to(BF).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(n, c, h, w, generator=g).to(DEV).to(BF).contiguous(memory_format=torch.channels_last) if res else None
+    w1 = (torch.randn(c, c, 3, generator=g) * 0.05).to(DEV)
+    w2 = (torch.randn(c, c, 3, generator=g) * 0.05).to(DEV)
+    b1 = (torch.randn(c, generator=g) * 0.1).to(DEV)
+    b2 = (torch.randn(c, generator=g) * 0.1).to(DEV)
+    packed = torch.empty(2 * 3 * c * c, dtype=BF, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.erf_conv_pair_pack_bf16(p(w1), p(w2), c, p(packed), st))
+    y = torch.zeros_like(x)
+    m = torch.zeros_like(x) if keep_mid else None
+    _lib.check(lib.erf_conv_pair_forward_bf16(p(x), p(packed), p(b1), p(b2), axis, d1, d2, 1, 1, p(r), p(m), p(y),
+                                              n, c, h, w, st))
+    torch.cuda.synchronize()
+    return (None if m is None else m.view(torch.int16).clone()), y.view(torch.int16).clone()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("n,c,h,w,axis,d1,d2,keep_mid,res", [
+    (6, 128, 64, 128, 1, 1, 2, True, True), (3, 128, 20, 200, 1, 2, 4, False, True), (5, 128, 64, 110, 1, 16, 16, True, False),
+    (4, 64, 100, 160, 1, 1, 1, True, False), (2, 64, 128, 300, 1, 2, 1, False, True), (9, 64, 64, 64, 1, 1, 8, True, True),
+    (3, 128, 200, 32, 0, 1, 2, True, True), (700, 128, 8, 8, 1, 1, 1, True, True)])
+def test_eight_wave_pair_kernel_is_bit_identical(n, c, h, w, axis, d1, d2, keep_mid, res):
+    """line2_bf16_kernel (conv_a of tile k+1 beside conv_b of tile k, eight waves) against
+    line_bf16_kernel on the same pair: identical bits in the intermediate and the output — lines
+    shorter than the tile, image borders inside the dilation, single-valid-tap columns, with and
+    without residual / stored intermediate."""
+    from erfnet_pytorch_amd import _lib
+    prev = _lib.set_option(_lib.OPT_LINE2, 0)
+    try:
+        n0 = _lib.launch_count()
+        ref = _pair_bf16(n, c, h, w, axis, d1, d2, keep_mid, res, 7)
+        _lib.set_option(_lib.OPT_LINE2, 1)
+        got = _pair_bf16(n, c, h, w, axis, d1, d2, keep_mid, res, 7)
+    finally:
+        _lib.set_option(_lib.OPT_LINE2, prev)
+    for u, v in zip(ref, got):
+        assert (u is None) == (v is None)
+        if u is not None:
+            assert torch.equal(u, v)
+
+
+@pytest.mark.timeout(120)
+def test_eight_wave_pair_kernel_in_a_training_step_is_bit_identical():
+    """The same comparison through a chain of blocks, forward and backward (residual in the first
+    epilogue, ReLU masks in both epilogues of the data-gradient pairs)."""
+    from erfnet_pytorch_amd import _lib, functional as hipf
+    g = torch.Generator().manual_seed(3)
+    c, d = 128, 2
+    x0 = torch.randn(6, c, 64, 128, generator=g).clamp_(min=0).to(DEV).to(BF).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(6, c, 64, 128, generator=g).to(DEV).to(BF).contiguous(memory_format=torch.channels_last)
+    blocks = []
+    for _ in range(3):
+        ws = [(torch.randn(c, c, *k, generator=g) * 0.05).to(DEV).requires_grad_(True) for k in ((3, 1), (1, 3), (3, 1), (1, 3))]
+        bs = [(torch.randn(c, generator=g) * 0.1).to(DEV).requires_grad_(True) for _ in range(4)]
+        blocks.append((ws, bs))
+
+    def run():
+        x = x0.clone().requires_grad_(True)
+        y = hipf.nb1d_chain(x, [dict(weights=ws, biases=bs, dilated=d, bn_mode=0, drop_scale=None) for ws, bs in blocks])
+        y.backward(gy)
+        out = [y.detach().view(torch.int16).clone(), x.grad.view(torch.int16).clone()]
+        for ws, bs in blocks:
+            for q in ws + bs:
+                out.append(q.grad.clone())
+                q.grad = None
+        return out
+
+    prev = _lib.set_option(_lib.OPT_LINE2, 0)
+    try:
+        ref = run()
+        _lib.set_option(_lib.OPT_LINE2, 1)
+        got = run()
+    finally:
+        _lib.set_option(_lib.OPT_LINE2, prev)
+    for i, (u, v) in enumerate(zip(ref, got)):
+        assert torch.equal(u, v), i
