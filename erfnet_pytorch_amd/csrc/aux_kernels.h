@@ -37,18 +37,39 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
     const int rem = (int)(m - (long long)n * Ho * Wo);
     const int oh = rem / Wo, ow = rem - oh * Wo;
     float xin[27];
+    // Image rows with unit pixel stride and even strides / base (NCHW images of even width): the three
+    // columns 2ow-1 .. 2ow+1 of a row come from two aligned pair loads, (2ow-2, 2ow-1) and (2ow, 2ow+1),
+    // each of which a wave reads as one contiguous run; otherwise element by element.
+    const bool pairs = d.sw == 1 && !((d.sn | d.sc | d.sh) & 1) && !((uintptr_t)d.x & (2 * Act<T>::B - 1));
+    if (pairs) {
 #pragma unroll
-    for (int ci = 0; ci < 3; ++ci)
+        for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
-                float v = 0.0f;
-                if (ih >= 0 && iw >= 0 && ih < d.H && iw < d.W)
-                    v = Act<T>::ld1(d.x, n * d.sn + ci * d.sc + ih * d.sh + iw * d.sw);
-                xin[ci * 9 + kh * 3 + kw] = v;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = 2 * oh - 1 + kh;
+                const bool rok = ih >= 0 && ih < d.H;
+                const long long e = n * d.sn + ci * d.sc + (long long)ih * d.sh + 2 * ow;
+                f32x2 lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+                if (rok && ow > 0) lo = Act<T>::ld2(d.x, e - 2);
+                if (rok) hi = Act<T>::ld2(d.x, e);
+                xin[ci * 9 + kh * 3 + 0] = lo[1];
+                xin[ci * 9 + kh * 3 + 1] = hi[0];
+                xin[ci * 9 + kh * 3 + 2] = hi[1];
             }
+    } else {
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = 2 * oh - 1 + kh, iw = 2 * ow - 1 + kw;
+                    float v = 0.0f;
+                    if (ih >= 0 && iw >= 0 && ih < d.H && iw < d.W)
+                        v = Act<T>::ld1(d.x, n * d.sn + ci * d.sc + ih * d.sh + iw * d.sw);
+                    xin[ci * 9 + kh * 3 + kw] = v;
+                }
+    }
     const long long o0 = m * Cout;
     if (d.Cc == 13 && !d.epi.nscale && !d.epi.res && !d.epi.mask) {
         // the network's own first block (3 -> 16 channels): all 16 outputs of the pixel are formed

@@ -155,6 +155,7 @@ template <> struct Act<float> {
     static __device__ __forceinline__ void st4(void *p, long long e, f32x4 v) { *reinterpret_cast<f32x4 *>((float *)p + e) = v; }
     static __device__ __forceinline__ void st1(void *p, long long e, float v) { ((float *)p)[e] = v; }
     static __device__ __forceinline__ void st2(void *p, long long e, f32x2 v) { *reinterpret_cast<f32x2 *>((float *)p + e) = v; }
+    static __device__ __forceinline__ f32x2 ld2(const void *p, long long e) { return *reinterpret_cast<const f32x2 *>((const float *)p + e); }
 };
 template <> struct Act<bf16_t> {
     static constexpr unsigned B = 2;
@@ -181,6 +182,11 @@ template <> struct Act<bf16_t> {
     static __device__ __forceinline__ float ld1(const void *p, long long e) { return bf16_to_f32(((const bf16_t *)p)[e]); }
     static __device__ __forceinline__ void st4(void *p, long long e, f32x4 v) { *reinterpret_cast<u32x2 *>((bf16_t *)p + e) = pack_bf16x4(v); }
     static __device__ __forceinline__ void st1(void *p, long long e, float v) { ((bf16_t *)p)[e] = f32_to_bf16(v); }
+    static __device__ __forceinline__ f32x2 ld2(const void *p, long long e)
+    {
+        const unsigned u = *reinterpret_cast<const unsigned *>((const bf16_t *)p + e);
+        return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+    }
     static __device__ __forceinline__ void st2(void *p, long long e, f32x2 v)
     {
         bf16x2 o;

@@ -993,6 +993,16 @@ int launch_up16_fwd(const IgemmDesc &d, hipStream_t st)
     if (M == 0) return 0;
     long long blocks = (M + 63) / 64;             // one 16-position tile per wave at least
     if (blocks > 768) blocks = 768;               // three resident blocks per CU share the weight fill
+    if (d.dt && d.in_C % 8 == 0 && d.in_coff % 8 == 0 && d.K % 16 == 0 && d.K <= 64) {     // bf16 tensors: bf16 MFMA
+        switch (d.K / 16) {
+        case 1: up16_fwd_bf16_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+        case 2: up16_fwd_bf16_kernel<2><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+        case 3: up16_fwd_bf16_kernel<3><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+        default: up16_fwd_bf16_kernel<4><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+        }
+        CHECK_LAUNCH("up16_fwd_bf16_kernel");
+        return 0;
+    }
     switch (d.K / 16) {
     case 1: BY_DT(d.dt, (up16_fwd_kernel<T, 1><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
     case 2: BY_DT(d.dt, (up16_fwd_kernel<T, 2><<<(unsigned)blocks, 256, 0, st>>>(d))); break;

@@ -120,6 +120,107 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
     }
 }
 
+// up16_fwd_kernel for bf16 tensors on v_mfma_f32_16x16x32_bf16: 32 coarse channels per instruction,
+// the bf16 data straight from memory as the MFMA operand (16-byte loads, no unpacking): 9 * NK MFMAs
+// of 16 cycles per 16 coarse positions instead of 9 * 4 * KQ of 32.  Weights in LDS as bf16
+// [tap][k / 32][c][32 k] (channels beyond K zero); lane (i, g) holds k = 32 kk + 8 g .. + 7.
+template <int KQ>
+__global__ __launch_bounds__(256) void up16_fwd_bf16_kernel(const IgemmDesc d)
+{
+    typedef bf16_t T;
+    constexpr int NK = (KQ + 1) / 2;
+    __shared__ __attribute__((aligned(16))) bf16_t Wl[9 * NK * 16 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    for (int idx = tid; idx < 9 * NK * 16 * 32; idx += 256) {
+        const int e = idx & 31, j = (idx >> 5) & 15, kk = (idx >> 9) % NK, t = idx / (NK * 512);
+        const int k = kk * 32 + e;
+        Wl[idx] = f32_to_bf16(k < 16 * KQ ? d.w[t + (long long)k * d.wsk + (long long)j * d.wsn] : 0.0f);
+    }
+    __syncthreads();
+
+    const unsigned H = (unsigned)d.GH, W = (unsigned)d.GW, M = (unsigned)d.N * H * W, HW = H * W;
+    const unsigned Pout = M * 4u;
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, M * d.in_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, Pout * d.out_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, Pout * d.epi.res_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
+    const bool has_mask = d.epi.mask != nullptr, relu = d.epi.relu != 0;
+
+    f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    f32x4 sh = buf_load4(r_bias, g * 16u);
+    if (d.epi.bn.on) {          // wave-uniform
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(d.epi.bn.gamma + 4 * g);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(d.epi.bn.beta + 4 * g);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(d.epi.bn.mean + 4 * g);
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(d.epi.bn.var + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = d.epi.bn.var_is_invstd ? va[r] : rsqrtf(va[r] + d.epi.bn.eps);
+            sc[r] = ga[r] * inv;
+            sh[r] = (sh[r] - mu[r]) * sc[r] + be[r];
+        }
+    }
+    // this lane's channels of MFMA kk: 32 kk + 8 g .. + 7 (beyond K: nothing is loaded, the weights are zero)
+    unsigned cbad[NK];
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) cbad[kk] = 32 * kk + 8 * g < 16 * KQ ? 0u : ERF_OOB;
+
+    const unsigned ntiles = (M + 15) / 16;
+    for (unsigned tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const unsigned p = tile * 16 + i;
+        const bool valid = p < M;
+        const unsigned pp = valid ? p : 0;
+        const unsigned n = pp / HW, rem = pp - n * HW;
+        const unsigned y = rem / W, x = rem - y * W;
+        u32x4 xs[4][NK];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned ys = y + (s >> 1), xx = x + (s & 1);
+            const unsigned bad = (valid && ys < H && xx < W) ? 0u : ERF_OOB;
+            const unsigned off = (((n * H + ys) * W + xx) * d.in_C + d.in_coff + 8 * g) * 2u;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk)
+                xs[s][kk] = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)((off + kk * 64u) | bad | cbad[kk]), 0, 0);
+        }
+        unsigned ooff[4];
+        f32x4 rres[4], rmask[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
+            ooff[c] = valid ? (px * d.out_C + d.out_coff + 4 * g) : ERF_OOB;
+            rres[c] = Act<T>::load4(r_res, valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) : ERF_OOB);
+            rmask[c] = Act<T>::load4(r_mask, valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) : ERF_OOB);
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+            bf16x8 wf[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                wf[t] = *reinterpret_cast<const bf16x8 *>(&Wl[((t * NK + kk) * 16 + i) * 32 + 8 * g]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc[S16_CLASS(t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t], __builtin_bit_cast(bf16x8, xs[S16_SRC(t)][kk]),
+                                                                            acc[S16_CLASS(t)], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = acc[c][r] * sc[r] + sh[r] + rres[c][r];
+                if (relu) e = fmaxf(e, 0.0f);
+                v[r] = (!has_mask || rmask[c][r] > 0.0f) ? e : 0.0f;
+            }
+            Act<T>::store4(r_out, ooff[c], v);
+        }
+    }
+}
+
 // dW[tap][k][j] = sum_pos coarse[pos + d(tap)][k] * fine[2 pos + class(tap)][j]   (k < 16*KQ, j < 16)
 // MFMA roles: row = k within its 16-channel quad, contraction = 4 consecutive coarse positions,
 // column = j.  Lane (i, g) reads one float per source/class of position 4u + g.  Each wave keeps
