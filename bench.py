@@ -428,6 +428,8 @@ def main():
                                                                   iters=10)["ms_per_img_min"]
                 rec["fullres_inference_bf16"] = full
                 rec["train_erfnet_bn"] = train_rate(device, "erfnet_bn", args.dtype, args.batch, 8, 3)
+                rec["train_erfnet_bn_other_dtype"] = train_rate(device, "erfnet_bn", "bf16" if args.dtype == "f32" else "f32",
+                                                                args.batch, 8, 3)
                 # BASELINE configs[4] per GPU: the ImageNet pre-training step of the encoder
                 rec["imagenet_pretrain"] = {"f32": imagenet_rate(device, "f32"),
                                             "bf16": imagenet_rate(device, "bf16")}

@@ -880,8 +880,16 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
         long long nsplit = (M + NW * 64 - 1) / (NW * 64);          // >= 4 MFMA groups per wave
         if (nsplit > 512) nsplit = 512;
         if (nsplit < 1) nsplit = 1;
+        // bf16 tensors whose channel slices allow 16-byte loads: bf16 MFMA, 32 pixels per instruction
+        static int no16 = -1;
+        if (no16 < 0) { const char *e = getenv("ERFNET_NO_WGRAD16_BF16"); no16 = (e && atoi(e)) ? 1 : 0; }
+        bool b16 = d.dt != 0 && !no16;
+        for (int i = 0; i < n; ++i)
+            b16 = b16 && dd[i].in_C % 8 == 0 && dd[i].in_coff % 8 == 0 && dd[i].g_C % 8 == 0 && dd[i].g_coff % 8 == 0 &&
+                  aligned16(dd[i].in) && aligned16(dd[i].g);
+        const int gran = NW * (b16 ? 32 : 16);
         long long sp = (M + nsplit - 1) / nsplit;
-        sp = (sp + NW * 16 - 1) / (NW * 16) * (NW * 16);
+        sp = (sp + gran - 1) / gran * gran;
         nsplit = (M + sp - 1) / sp;
         for (int i = 0; i < n; ++i) {
             WgradDesc &e = dd[i];
@@ -889,7 +897,8 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
             e.split_pixels = (int)sp;
             e.partial = ar.floats(slab * nsplit);
             if (!e.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
-            BY_DT(d.dt, (wgrad16_kernel<T, 3, NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e)));
+            if (b16) wgrad16_bf16_kernel<NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e);
+            else BY_DT(d.dt, (wgrad16_kernel<T, 3, NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e)));
             CHECK_LAUNCH("wgrad16_kernel");
         }
         return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);

@@ -560,3 +560,101 @@ __global__ __launch_bounds__(256) void conv16_bf16_kernel(const IgemmDesc d)
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// wgrad16_kernel for bf16 tensors on v_mfma_f32_16x16x32_bf16 (32 pixels per instruction).  The
+// contraction index is the pixel while memory holds [pixel][channel]: a wave stages 32 pixels of G and
+// of X shifted by each tap (zero outside the image: three 16-byte loads per lane instead of forty-eight
+// 2-byte ones) in its own 4 KiB of LDS and takes the operand fragments out with the transposing read
+// ds_read_b64_tr_b16 (lane (i, g): channel i, pixels 8g..8g+7).  Slab output as wgrad16_kernel.
+__device__ __forceinline__ bf16x8 tr_frag16(const unsigned char *tile, int lane)
+{
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const unsigned char *a = tile + (8 * g + q) * 32 + 8 * p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(a + 4 * 32));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad16_bf16_kernel(const WgradDesc d)
+{
+    constexpr int NTAPS = 3, SLOTS = NTAPS * 256 + 16;
+    __shared__ float red[NW][SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[NW][4][32 * 32];     // G, X(tap 0..2): [32 px][16 ch] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int pl = lane >> 1, half = lane & 1;              // staging role: pixel of the chunk, channel half
+    const unsigned M = (unsigned)d.N * d.GH * d.GW;
+    const unsigned H = (unsigned)d.GH, W = (unsigned)d.GW;
+    const unsigned wsp = (unsigned)d.split_pixels / NW;              // multiple of 32 (host)
+    const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
+    unsigned wend = wbeg + wsp;
+    if (wend > M) wend = M;
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, M * d.in_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, M * d.g_C * 2u);
+
+    f32x4 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum = 0.0f;
+
+    // (row, column) of this lane's staging pixel, advanced by 32 pixels per chunk
+    unsigned q0 = (wbeg < M ? wbeg : 0u) + pl;
+    unsigned oh = (q0 / W) % H, ow = q0 % W;
+    u32x4 rg, rx[NTAPS];
+    auto load_chunk = [&](unsigned m0) __attribute__((always_inline)) {
+        const unsigned m = m0 + pl;
+        const bool valid = m < wend;
+        rg = __builtin_amdgcn_raw_buffer_load_b128(r_g, (int)(valid ? (m * d.g_C + d.g_coff + 8 * half) * 2u : ERF_OOB), 0, 0);
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int ih = (int)oh + d.tdh[t], iw = (int)ow + d.tdw[t];
+            const bool ok = valid && (unsigned)ih < H && (unsigned)iw < W;
+            const unsigned off = ((unsigned)((int)m + d.tdh[t] * (int)W + d.tdw[t]) * d.in_C + d.in_coff + 8 * half) * 2u;
+            rx[t] = __builtin_amdgcn_raw_buffer_load_b128(r_x, (int)(ok ? off : ERF_OOB), 0, 0);
+        }
+        ow += 32;
+        while (ow >= W) { ow -= W; oh = oh + 1 == H ? 0u : oh + 1; }
+    };
+    unsigned char *st = &stage[wave][0][0];
+    if (wbeg < wend) load_chunk(wbeg);
+    for (unsigned m0 = wbeg; m0 < wend; m0 += 32) {
+        *reinterpret_cast<u32x4 *>(st + pl * 32 + half * 16) = rg;
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) *reinterpret_cast<u32x4 *>(st + (1 + t) * 1024 + pl * 32 + half * 16) = rx[t];
+        if (m0 + 32 < wend) load_chunk(m0 + 32);
+        __builtin_amdgcn_wave_barrier();
+        const bf16x8 gf = tr_frag16(st, lane);
+        bf16x8 xf[NTAPS];
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) xf[t] = tr_frag16(st + (1 + t) * 1024, lane);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum += (float)gf[e];
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t], gf, acc[t], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t * 256 + (4 * g + r) * 16 + i] = acc[t][r];
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (g == 0) red[wave][NTAPS * 256 + i] = bsum;
+    __syncthreads();
+    float *P = d.partial + (long long)blockIdx.x * (NTAPS * 256 + NTAPS * 16);
+    for (int e = tid; e < SLOTS; e += NW * 64) {
+        float s = red[0][e];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[w][e];
+        if (e < NTAPS * 256) P[e] = s;
+        else
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) P[NTAPS * 256 + t * 16 + (e - NTAPS * 256)] = s;
+    }
+}

@@ -1,5 +1,5 @@
 """Training-step throughput of eval/erfnet.py's ERFNet(20) (BatchNorm in train mode, Dropout2d) at
-batch 6, 512x1024 — the BatchNorm counterpart of bench.py's workload."""
+batch 6, 512x1024 — the BatchNorm counterpart of bench.py's workload: `train_bn.py [f32|bf16]`."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -13,7 +13,8 @@ m = erfnet.ERFNet(20).to(dev).train()
 opt = torch.optim.Adam(m.parameters(), 1e-4, eps=1e-4, weight_decay=1e-6, fused=True)
 red = GradientReducer(m, direct_write=True)
 crit = CrossEntropyLoss2d()
-x = torch.rand(B, 3, 512, 1024, device=dev); lab = torch.randint(-1, 20, (B, 512, 1024), device=dev)
+dt_ = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
+x = torch.rand(B, 3, 512, 1024, device=dev).to(dt_); lab = torch.randint(-1, 20, (B, 512, 1024), device=dev)
 def step():
     red.zero_grad()
     loss = crit(m(x), lab); loss.backward(); red.finish(); opt.step()
