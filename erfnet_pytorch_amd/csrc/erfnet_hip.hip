@@ -1033,8 +1033,14 @@ int launch_up16_wgrad(WgradDesc &d, float *dw, float *db, int wsk, int wsn, int 
     long long nsplit = (M + 255) / 256;           // 64 positions per wave at least
     if (nsplit > 512) nsplit = 512;
     if (nsplit < 1) nsplit = 1;
+    // bf16 tensors whose channel slices allow 16-byte loads: bf16 MFMA, 32 positions per instruction
+    static int no16 = -1;
+    if (no16 < 0) { const char *e = getenv("ERFNET_NO_WGRAD16_BF16"); no16 = (e && atoi(e)) ? 1 : 0; }
+    const bool b16 = d.dt != 0 && !no16 && d.in_C % 8 == 0 && d.in_coff % 8 == 0 && d.g_C % 8 == 0 && d.g_coff % 8 == 0 &&
+                     aligned16(d.in) && aligned16(d.g);
+    const int gran = b16 ? 128 : 16;
     long long sp = (M + nsplit - 1) / nsplit;
-    sp = (sp + 15) / 16 * 16;
+    sp = (sp + gran - 1) / gran * gran;
     nsplit = (M + sp - 1) / sp;
     d.nsplit = (int)nsplit;
     d.split_pixels = (int)sp;
@@ -1042,7 +1048,8 @@ int launch_up16_wgrad(WgradDesc &d, float *dw, float *db, int wsk, int wsn, int 
     d.partial = ar.floats(slab * nsplit);
     if (!d.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
     // one 16-channel quad of the coarse side per block (blockIdx.y)
-    BY_DT(d.dt, (up16_wgrad_kernel<T, 1><<<dim3((unsigned)nsplit, KQ, 1), 256, 0, st>>>(d)));
+    if (b16) up16_wgrad_bf16_kernel<<<dim3((unsigned)nsplit, KQ, 1), 256, 0, st>>>(d);
+    else BY_DT(d.dt, (up16_wgrad_kernel<T, 1><<<dim3((unsigned)nsplit, KQ, 1), 256, 0, st>>>(d)));
     CHECK_LAUNCH("up16_wgrad_kernel");
     ReduceBatch rb;
     memset(&rb, 0, sizeof(rb));

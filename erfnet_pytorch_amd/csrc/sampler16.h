@@ -356,3 +356,130 @@ __global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
         for (int e = tid; e < 9 * 16; e += 256) P[nwt + e] = e < 16 ? red[NW_ + e] : 0.0f;
     for (int e = tid; e < 16 * KQ; e += 256) P[nwt + 9 * 16 + 16 * q0 + e] = red[NW_ + 16 + e];
 }
+
+// up16_wgrad_kernel for bf16 tensors on v_mfma_f32_16x16x32_bf16: 32 coarse positions per instruction.
+// A wave stages, for 32 positions, the four coarse sources (its block's 16-channel quad) and the four
+// fine classes as [32][16] bf16 tiles in its own 8 KiB of LDS (eight 16-byte loads per lane instead of
+// sixty-four scalar ones) and takes the operands out with the transposing read (tr_frag16: lane
+// (i, g) = channel i, positions 8g..8g+7).  One quad per block (blockIdx.y), slab as up16_wgrad_kernel.
+__device__ __forceinline__ bf16x8 s16_tr_frag(const unsigned char *tile, int lane)
+{
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const unsigned char *a = tile + (8 * g + q) * 32 + 8 * p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(a + 4 * 32));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void up16_wgrad_bf16_kernel(const WgradDesc d)
+{
+    constexpr int NW_ = 9 * 256, SLOTS = NW_ + 16 + 16;
+    __shared__ float red[SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[4][8][32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int pl = lane >> 1, half = lane & 1;
+    const int q0 = blockIdx.y, KQT = d.K / 16;
+    const unsigned H = (unsigned)d.GH, W = (unsigned)d.GW, M = (unsigned)d.N * H * W, HW = H * W;
+    const unsigned wsp = (unsigned)d.split_pixels / 4;            // multiple of 32 (host)
+    const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
+    unsigned wend = wbeg + wsp;
+    if (wend > M) wend = M;
+    const __amdgpu_buffer_rsrc_t r_c = make_rsrc(d.in, M * d.in_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_f = make_rsrc(d.g, M * 4u * d.g_C * 2u);
+
+    f32x4 acc[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) acc[a] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float fsum = 0.0f, csum = 0.0f;
+
+    unsigned cn, cy, cx;        // coordinates of this lane's staging position, advanced by 32 per chunk
+    {
+        const unsigned p0 = (wbeg < M ? wbeg : 0u) + pl;
+        cn = p0 / HW;
+        const unsigned rem = p0 - cn * HW;
+        cy = rem / W;
+        cx = rem - cy * W;
+    }
+    u32x4 rc[4], rf[4];
+    auto load_chunk = [&](unsigned m0) __attribute__((always_inline)) {
+        const bool valid = m0 + pl < wend;
+        const unsigned n = cn, y = cy, x = cx;
+        cx += 32;
+        while (cx >= W) {
+            cx -= W;
+            if (++cy == H) { cy = 0; ++cn; }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned ys = y + (s >> 1), xx = x + (s & 1);
+            const bool ok = valid && ys < H && xx < W;
+            const unsigned off = (((n * H + ys) * W + xx) * d.in_C + d.in_coff + 16 * q0 + 8 * half) * 2u;
+            rc[s] = __builtin_amdgcn_raw_buffer_load_b128(r_c, (int)(ok ? off : ERF_OOB), 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
+            rf[c] = __builtin_amdgcn_raw_buffer_load_b128(r_f, (int)(valid ? (px * d.g_C + d.g_coff + 8 * half) * 2u : ERF_OOB), 0, 0);
+        }
+    };
+    unsigned char *st = &stage[wave][0][0];
+    if (wbeg < wend) load_chunk(wbeg);
+    for (unsigned m0 = wbeg; m0 < wend; m0 += 32) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<u32x4 *>(st + s * 1024 + pl * 32 + half * 16) = rc[s];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4 *>(st + (4 + c) * 1024 + pl * 32 + half * 16) = rf[c];
+        if (m0 + 32 < wend) load_chunk(m0 + 32);
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 cf[4], ff[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cf[s] = s16_tr_frag(st + s * 1024, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ff[c] = s16_tr_frag(st + (4 + c) * 1024, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fsum += (float)ff[c][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csum += (float)cf[0][e];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[S16_SRC(t)], ff[S16_CLASS(t)], acc[t], 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
+    fsum += __shfl_xor(fsum, 16);
+    fsum += __shfl_xor(fsum, 32);
+    csum += __shfl_xor(csum, 16);
+    csum += __shfl_xor(csum, 32);
+    // block reduction: the waves add into LDS one after the other (fixed order)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < 9; ++a)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = (a * 16 + 4 * g + r) * 16 + i;        // tap a, row k = 4g + r, column j = i
+                    red[e] = (w ? red[e] : 0.0f) + acc[a][r];
+                }
+            if (g == 0) {
+                red[NW_ + i] = (w ? red[NW_ + i] : 0.0f) + fsum;
+                red[NW_ + 16 + i] = (w ? red[NW_ + 16 + i] : 0.0f) + csum;
+            }
+        }
+        __syncthreads();
+    }
+    const int nwt = 9 * KQT * 256;
+    const int slab = nwt + 9 * 16 + 16 * KQT;
+    float *P = d.partial + (long long)blockIdx.x * slab;
+    for (int e = tid; e < NW_; e += 256) {
+        const int t = e / 256, rest = e - t * 256;
+        P[(t * KQT + q0) * 256 + rest] = red[e];
+    }
+    if (blockIdx.y == 0)
+        for (int e = tid; e < 9 * 16; e += 256) P[nwt + e] = e < 16 ? red[NW_ + e] : 0.0f;
+    for (int e = tid; e < 16; e += 256) P[nwt + 9 * 16 + 16 * q0 + e] = red[NW_ + 16 + e];
+}
