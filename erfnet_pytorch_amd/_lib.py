@@ -77,6 +77,9 @@ _PROTOS = {
     "erf_nb1d_chain_forward": (C.c_int, [vp, C.POINTER(Nb1dBlockStruct), C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, vp, C.c_size_t, vp]),
     "erf_conv_pair_pack": (C.c_int, [vp, vp, C.c_int, vp, vp]),
+    "erf_conv_line_pack_split": (C.c_int, [vp, C.c_int, vp, vp]),
+    "erf_conv_line_forward_split": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, vp]),
     "erf_conv_pair_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                         vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "erf_nb1d_backward": (C.c_int, [vp, C.POINTER(vp), C.POINTER(BnStruct), C.POINTER(BnStruct), vp,
@@ -127,7 +130,7 @@ _PROTOS["erf_outconv_forward_bf16"] = (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_in
                                                  C.c_int, C.c_int, vp])
 
 BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
-OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16, OPT_PAIR16, OPT_LINE2 = 1, 2, 3, 4, 5
+OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16, OPT_PAIR16, OPT_LINE2, OPT_SPLIT_BF16 = 1, 2, 3, 4, 5, 6
 
 EXPORTS = tuple(_PROTOS)
 

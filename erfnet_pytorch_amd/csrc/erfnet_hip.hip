@@ -8,6 +8,7 @@
 #include "pair.h"
 #include "line_bf16.h"
 #include "line2_bf16.h"
+#include "line_x3.h"
 #include "igemm_bf16.h"
 #include "wgrad_line.h"
 #include "wgrad_line_bf16.h"
@@ -56,6 +57,9 @@ Switch g_sw_pair("ERFNET_NO_PAIR"), g_sw_wgrad_line("ERFNET_NO_WGRAD_LINE"), g_s
 // memory-bound, at 16 channels); ERFNET_PAIR16=1 or ERF_OPT_PAIR16 turns it on
 Switch g_sw_pair16("ERFNET_PAIR16", 0);
 std::atomic<int> g_line2{1};        // ERF_OPT_LINE2
+// fp32 64 / 128-channel 1-D convolutions on the bf16 matrix pipe, operands split in three bf16 terms
+// (line_x3_kernel); ERFNET_X3=1 or ERF_OPT_SPLIT_BF16 turns it on
+Switch g_sw_x3("ERFNET_X3", 0);
 
 int fail(const char *fmt, ...)
 {
@@ -152,10 +156,11 @@ int line_tile_bf16(int NC, int L, bool pair)
 
 size_t line_packed_elems(int NC) { return (size_t)3 * NC * NC; }
 
-void line_pack_desc(LinePackDesc &k, const float *w, bf16_t *wp, int NC, int wsk, int wsn, const int *woff)
+void line_pack_desc(LinePackDesc &k, const float *w, bf16_t *wp, int NC, int wsk, int wsn, const int *woff,
+                    bool x3 = false)
 {
     memset(&k, 0, sizeof(k));
-    k.w = w; k.wp = wp; k.NC = NC; k.wsk = wsk; k.wsn = wsn;
+    k.w = w; k.wp = wp; k.NC = NC; k.wsk = wsk; k.wsn = wsn; k.x3 = x3 ? 1 : 0;
     for (int t = 0; t < 3; ++t) k.woff[t] = woff[t];
 }
 
@@ -246,6 +251,27 @@ bool line_geometry(const IgemmDesc &d, LineDesc &ld, bool reads_memory = true)
     return true;
 }
 const int kCfgLine = 101;
+// the same geometry on fp32 tensors (line_x3_kernel): byte offsets must stay below 2^31
+const int kCfgLineX3 = 102;
+bool line_x3_ok(const IgemmDesc &d, LineDesc &ld)
+{
+    if (d.dt || !g_sw_x3.on()) return false;
+    if ((long long)d.N * d.GH * d.GW * d.K >= (1LL << 29)) return false;
+    return line_geometry(d, ld);
+}
+int run_line_x3(LineDesc ld, int NC, hipStream_t st)
+{
+    const int BM = NC == 128 ? 64 : 128;
+    ld.segs = (ld.L + BM - 1) / BM;
+    const int ntiles = ld.nlines * ld.segs;
+    if (ntiles <= 0) return 0;
+    const int cus = cu_count();
+    const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+    if (NC == 128) line_x3_kernel<128, 64><<<grid, 256, 0, st>>>(ld);
+    else line_x3_kernel<64, 128><<<grid, 256, 0, st>>>(ld);
+    CHECK_LAUNCH("line_x3_kernel");
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------- igemm launch
 // Tile configurations <WM, WN, GM, GN>: block tile BM = GM*WM*32 pixels x BN = GN*WN*32 channels.
@@ -343,6 +369,21 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
             return fail("igemm: tensors of 2 GiB or more are not supported");
     }
     d.vec_ok = (d.in_C % 4 == 0 && d.in_coff % 4 == 0 && d.K % 4 == 0 && aligned16(d.in)) ? 1 : 0;
+    {
+        LineDesc ld;
+        if (line_x3_ok(d, ld)) {     // fp32 on the bf16 matrix pipe: three weight planes
+            bf16_t *wp = (bf16_t *)ar.take(3 * line_packed_elems(d.K) * sizeof(bf16_t));
+            if (!wp) return fail("igemm: workspace too small for the weight fragments");
+            d.cfg = kCfgLineX3;
+            d.Npad = d.Nout;
+            d.wp = wp;
+            memset(&pk, 0, sizeof(pk));
+            pk.w = d.w; pk.K = d.K; pk.Nout = d.Nout; pk.wsk = d.wsk; pk.wsn = d.wsn;
+            for (int t = 0; t < 3; ++t) pk.woff[t] = d.woff[t];
+            pk.line = 2; pk.lwp = wp;
+            return 0;
+        }
+    }
     if (d.dt) {          // bf16: the 64 / 128-channel 1-D convolutions take the line kernel
         LineDesc ld;
         if (line_geometry(d, ld)) {
@@ -419,7 +460,7 @@ int launch_pack(const PackDesc *pks, int n, hipStream_t st)
         int nl = 0;
         for (int i = 0; i < n; ++i) {
             if (!pks[i].line) continue;
-            line_pack_desc(lp[nl++], pks[i].w, pks[i].lwp, pks[i].K, pks[i].wsk, pks[i].wsn, pks[i].woff);
+            line_pack_desc(lp[nl++], pks[i].w, pks[i].lwp, pks[i].K, pks[i].wsk, pks[i].wsn, pks[i].woff, pks[i].line == 2);
             if (nl == ERF_LINE_PACK_BATCH) { if (launch_line_pack(lp, nl, st)) return 1; nl = 0; }
         }
         if (nl && launch_line_pack(lp, nl, st)) return 1;
@@ -456,6 +497,12 @@ int run_igemm_t(const IgemmDesc &d, hipStream_t st)
         const int BM = line_tile_bf16(d.K, ld.L, false);
         ld.segs = (ld.L + BM - 1) / BM;
         return run_line(ld, d.K, BM, false, st);
+    }
+    if (d.cfg == kCfgLineX3) {
+        LineDesc ld;
+        if (!line_geometry(d, ld)) return fail("igemm: line plan without line geometry");
+        ld.wp1 = (const bf16_t *)d.wp;
+        return run_line_x3(ld, d.K, st);
     }
     if (d.cfg == kCfgStream16) {
         // tile groups per wave: the per-wave set-up (descriptors, weights, coordinates) is paid once,
@@ -599,6 +646,7 @@ int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = fa
         if (la.pstride == lb.pstride) return 0;             // same axis: not a pair
         return line_tile_bf16(NC, la.L, true);
     }
+    if (!ignore_switch && g_sw_x3.on()) return 0;      // each half takes line_x3_kernel (faster than the fp32 pair)
     const IgemmDesc *dd[2] = {&a, &b};
     for (const IgemmDesc *d : dd) {
         if (d->K != NC || d->Nout != NC || d->in_C != NC || d->out_C != NC || d->in_coff || d->out_coff) return 0;
@@ -813,7 +861,11 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     // 128 channels: one 512-thread block per CU owns all 128 x 128 x 3 outputs (X is staged once);
     // 64 channels: three 256-thread blocks per CU
     const int jtiles = 1;
-    const int slots = NC == 128 ? 256 : 768;
+    // fp32 tensors on the bf16 matrix pipe (split operands): one block per CU; at 64 channels the
+    // block's two wave groups write a slab each
+    const bool x3 = !dd[0].dt && g_sw_x3.on();
+    const int kgroups = x3 && NC == 64 ? 2 : 1;
+    const int slots = (NC == 128 || x3) ? 256 : 768;
     const size_t slab = (size_t)3 * NC * NC + 3 * NC;
     WgradLineBatch wb;
     memset(&wb, 0, sizeof(wb));
@@ -837,14 +889,17 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
         WgradDesc &e = dd[i];
         WgradLineDesc &q = wb.d[i];
         q.spb = (q.nseg + nsplit - 1) / nsplit;
-        e.nsplit = nsplit;
-        e.partial = ar.floats(slab * nsplit);
-        if (!e.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit * n);
+        e.nsplit = nsplit * kgroups;
+        e.partial = ar.floats(slab * e.nsplit);
+        if (!e.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * e.nsplit * n);
         q.partial = e.partial;
     }
     const int max_split = nsplit;
     dim3 grid((unsigned)max_split, jtiles, n);
-    if (dd[0].dt) {         // bf16 tensors: bf16 MFMA, fragments through the transposing LDS read
+    if (x3) {
+        if (NC == 128) wgrad_line_x3_kernel<128, 1, 2, 4, 2, 1, 1><<<grid, 512, 0, st>>>(wb);
+        else wgrad_line_x3_kernel<64, 1, 1, 2, 2, 2, 1><<<grid, 512, 0, st>>>(wb);
+    } else if (dd[0].dt) {         // bf16 tensors: bf16 MFMA, fragments through the transposing LDS read
         if (NC == 128) wgrad_line_bf16_kernel<128, 1, 2, 4, 2, 1><<<grid, 512, 0, st>>>(wb);
         else wgrad_line_bf16_kernel<64, 1, 1, 2, 2, 3><<<grid, 256, 0, st>>>(wb);
     } else if (NC == 128) wgrad_line_kernel<128, 1, 2, 4, 2, 1, float><<<grid, 512, 0, st>>>(wb);
@@ -1330,6 +1385,7 @@ int erf_set_option(int option, int value)
     if (option == ERF_OPT_STREAM16) return g_sw_stream16.set(value);
     if (option == ERF_OPT_PAIR16) return g_sw_pair16.set(value);
     if (option == ERF_OPT_LINE2) return g_line2.exchange(value ? 1 : 0);
+    if (option == ERF_OPT_SPLIT_BF16) return g_sw_x3.set(value);
     return -1;
 }
 const char *erf_last_error(void) { return g_err; }
@@ -1714,6 +1770,46 @@ int erf_conv_pair_forward(const float *x, const float *packed, const float *b_fi
     }
     pd.nlines = N * pd.lines_per_img;
     return run_pair_f32(pd, C, tile, (hipStream_t)stream);
+}
+
+// One 3-tap 1-D convolution C -> C on fp32 tensors through line_x3_kernel (split-bf16 arithmetic),
+// whatever ERF_OPT_SPLIT_BF16 says: packed = 3 planes x 3*C*C bf16.
+int erf_conv_line_pack_split(const float *w, int C, void *packed, void *stream)
+{
+    if (C != 64 && C != 128) return fail("conv line (split): 64 or 128 channels (got %d)", C);
+    if (!w || !packed) return fail("conv line (split): null weight pointer");
+    LinePackDesc pk;
+    const int woff[3] = {0, 1, 2};
+    line_pack_desc(pk, w, (bf16_t *)packed, C, 3, C * 3, woff, true);
+    return launch_line_pack(&pk, 1, (hipStream_t)stream);
+}
+
+int erf_conv_line_forward_split(const float *x, const void *packed, const float *bias, int axis, int dil, int relu,
+                                const float *residual, const float *mask, float *y, int N, int C, int H, int W,
+                                void *stream)
+{
+    if (C != 64 && C != 128) return fail("conv line (split): 64 or 128 channels (got %d)", C);
+    if (axis != 0 && axis != 1) return fail("conv line (split): axis is 0 (H) or 1 (W)");
+    if (dil < 1) return fail("conv line (split): dilation must be >= 1");
+    if (!x || !packed || !y) return fail("conv line (split): null tensor pointer");
+    if (y == x) return fail("conv line (split): the output must not alias the input");
+    if (!aligned16(x) || !aligned16(y) || !aligned16(residual) || !aligned16(mask) || !aligned16(packed))
+        return fail("conv line (split): tensors must be 16-byte aligned");
+    if ((long long)N * H * W * C >= (1LL << 29)) return fail("conv line (split): tensor too large");
+    LineDesc ld;
+    memset(&ld, 0, sizeof(ld));
+    ld.in = (const bf16_t *)x; ld.wp1 = (const bf16_t *)packed; ld.out = (bf16_t *)y;
+    ld.epi1 = kNoEpi; ld.epi2 = kNoEpi;
+    ld.epi1.bias = bias; ld.epi1.relu = relu ? 1 : 0;
+    if (residual) { ld.epi1.res = residual; ld.epi1.res_C = C; }
+    if (mask) { ld.epi1.mask = mask; ld.epi1.mask_C = C; }
+    ld.N = N; ld.img_pixels = H * W;
+    // the taps run across the lines: a convolution along W takes image columns as lines
+    if (axis == 1) { ld.lines_per_img = W; ld.L = H; ld.pstride = W; ld.qstride = 1; }
+    else { ld.lines_per_img = H; ld.L = W; ld.pstride = 1; ld.qstride = W; }
+    for (int t = 0; t < 3; ++t) ld.s1[t] = (t - 1) * dil;
+    ld.nlines = N * ld.lines_per_img;
+    return run_line_x3(ld, C, (hipStream_t)stream);
 }
 
 int erf_conv_pair_pack_bf16(const float *w_first, const float *w_second, int C, void *packed, void *stream)

@@ -39,7 +39,7 @@ struct PackDesc {
     float *wp;
     int ntaps, K, Nout, Npad, wsk, wsn, kc;    // kc = channels per K-step (16 or 32); 0 = nothing to pack here
     int woff[ERF_MAX_TAPS];
-    int line;                                  // 1 = bf16 MFMA fragments for the line kernel (K = Nout = 64 / 128) into lwp
+    int line;                                  // 1 = bf16 MFMA fragments for the line kernel (K = Nout = 64 / 128) into lwp; 2 = three split planes
     bf16_t *lwp;
     int bf16;                                  // 1 = wp receives bf16 values (igemm_bf16_kernel), same order
 };

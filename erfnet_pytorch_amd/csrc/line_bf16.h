@@ -51,6 +51,7 @@ struct LinePackDesc {
     bf16_t *wp;
     int NC, wsk, wsn;           // W[tap][k][j] = w[woff[tap] + k*wsk + j*wsn]
     int woff[3];
+    int x3;                     // 1 = three planes wp[plane][...]: the value split into bf16 hi + mid + lo (line_x3_kernel)
 };
 #define ERF_LINE_PACK_BATCH 32
 struct LinePackBatch {
@@ -68,7 +69,15 @@ __global__ __launch_bounds__(256) void line_pack_kernel(const LinePackBatch b)
         const int cg = r % GC; r /= GC;
         const int s = r % KS, t = r / KS;
         const int ch = 32 * cg + (lane & 31), k = 16 * s + 8 * (lane >> 5) + j;
-        d.wp[idx] = f32_to_bf16(d.w[d.woff[t] + (long long)k * d.wsk + (long long)ch * d.wsn]);
+        const float v = d.w[d.woff[t] + (long long)k * d.wsk + (long long)ch * d.wsn];
+        const bf16_t hi = f32_to_bf16(v);
+        d.wp[idx] = hi;
+        if (d.x3) {
+            const float r1 = v - bf16_to_f32(hi);
+            const bf16_t mid = f32_to_bf16(r1);
+            d.wp[total + idx] = mid;
+            d.wp[2 * total + idx] = f32_to_bf16(r1 - bf16_to_f32(mid));
+        }
     }
 }
 

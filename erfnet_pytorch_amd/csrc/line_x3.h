@@ -1,0 +1,366 @@
+// 1-D convolution of a non_bottleneck_1d on fp32 activations, computed on the bf16 matrix pipe
+// (gfx950, v_mfma_f32_32x32x16_bf16) with every fp32 operand split into three bf16 terms:
+//
+//   x = xh + xm + xl,   xh = bf16(x), xm = bf16(x - xh), xl = bf16(x - xh - xm)      (exact: 3 x 8 bits)
+//   x * w  ~=  xh wh + xh wm + xm wh + xm wm + xh wl + xl wh
+//
+// Each bf16 product is exact in the fp32 accumulator; the three dropped terms (xm wl, xl wm, xl wl)
+// are below 2^-24 of |x w|, i.e. below the rounding of one fp32 multiply-add.  Six bf16 MFMAs per
+// k-step against one fp32 MFMA sixteen times slower: 2.7x the fp32 matrix rate at fp32 accuracy.
+// Non-finite inputs give NaN (inf - inf in the split); values within 2^-8 of FLT_MAX overflow.
+//
+// Structure (one wave per SIMD, 256 threads, persistent blocks as line_bf16_kernel):
+//   * weights STATIONARY IN REGISTERS as MFMA fragments, three planes (hi / mid / lo), packed by
+//     line_pack_kernel: 3 planes x 3 taps x NC/16 k-steps x 4 registers = 288 at NC = 128;
+//   * the operand tile of a tap is read from global memory as fp32 one tap AHEAD into registers, split
+//     and written to LDS as three bf16 planes [pixel][NC] (swizzled as in line_bf16_kernel) while the
+//     MFMAs of the current tap run; the split arithmetic, the LDS fragment reads of the next k-step
+//     and the global loads of the tap after next are cut into pieces placed one behind each MFMA;
+//   * fp32 epilogue through an fp32 LDS tile (residual by LDS-DMA, coalesced mask / store pass).
+#pragma once
+#include "line_bf16.h"
+
+// x - (bf16 pair as fp32)
+__device__ __forceinline__ f32x2 x3_sub_bf16x2(f32x2 x, unsigned p)
+{
+    return f32x2{x[0] - __builtin_bit_cast(float, p << 16), x[1] - __builtin_bit_cast(float, p & 0xffff0000u)};
+}
+__device__ __forceinline__ unsigned x3_cvt2(f32x2 v)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32 (RNE)
+}
+
+template <int NC, int BM>
+__global__ __launch_bounds__(256, 1) void line_x3_kernel(const LineDesc d)
+{
+    constexpr int GC = NC / 32, GP = 4 / GC, WM = BM / (32 * GP);
+    static_assert(WM == 2 && WM * GP * 32 == BM, "tile shape: two 32-pixel MFMA tiles per wave");
+    constexpr int KS = NC / 16;                 // MFMA k-steps per tap
+    constexpr int PITCH = NC * 2;               // bytes per pixel row of a bf16 plane
+    constexpr int TP = BM * PITCH, T3 = 3 * TP; // one plane, one operand tile (three planes)
+    constexpr int F4R = NC / 4;                 // 16-byte chunks per fp32 pixel row
+    constexpr int FPITCH = NC * 4, TF = BM * FPITCH;
+    constexpr int RPP = 256 / F4R;              // rows per copy pass of the block
+    constexpr int PASSES = BM / RPP;            // float4 per thread and tile
+    static_assert(PASSES % KS == 0 && PASSES / KS <= 2, "conversions per k-step");
+    constexpr int PER = PASSES / KS;
+    constexpr int OFF_TAP = 0, OFF_RES = 2 * T3, OFF_CST = OFF_RES + TF;
+    static_assert(OFF_CST + 2 * NC * 4 <= 160 * 1024, "LDS budget");
+    constexpr size_t PL = (size_t)3 * NC * NC;  // elements per weight plane
+    __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_CST + 2 * NC * 4];
+    float *cst = reinterpret_cast<float *>(lds + OFF_CST);          // sc[NC] sh[NC]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave % GC, wp = wave / GC;
+    const int l31 = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds;
+
+    const int L = d.L;
+    const int ntiles = d.nlines * d.segs;
+    const int nblk = gridDim.x;
+    const int b0 = (int)xcd_tile(blockIdx.x, nblk);
+    const int s1a = d.s1[0], s1b = d.s1[1], s1c = d.s1[2];
+    const bool has_res = d.epi1.res != nullptr;
+    const int K = b0 < ntiles ? (ntiles - b0 + nblk - 1) / nblk : 0;        // tiles of this block
+    if (K == 0) return;
+
+    const float *in = reinterpret_cast<const float *>(d.in);
+    float *out = reinterpret_cast<float *>(d.out);
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, (unsigned)((size_t)d.N * d.img_pixels * NC * 4));
+
+    struct Geo { int q; unsigned base; int len; };
+    auto geo = [&](int tile) __attribute__((always_inline)) {
+        Geo g;
+        const int line = tile / d.segs, seg = tile - line * d.segs;
+        const int n = line / d.lines_per_img;
+        g.q = line - n * d.lines_per_img;
+        const int r0 = seg * BM;
+        g.len = L - r0 < BM ? L - r0 : BM;
+        g.base = (unsigned)n * d.img_pixels + (unsigned)g.q * d.qstride + (unsigned)r0 * d.pstride;
+        return g;
+    };
+    auto tap_shift = [&](int t) __attribute__((always_inline)) { return t == 0 ? s1a : (t == 1 ? s1b : s1c); };
+    auto tap_valid = [&](const Geo &g, int t) __attribute__((always_inline)) {
+        return (unsigned)(g.q + tap_shift(t)) < (unsigned)d.lines_per_img;
+    };
+    // The block consumes a STREAM of operand tiles: the valid taps of its first line tile, then of
+    // its second, ...  A cursor names one of them (dead = past the end: loads nothing).
+    struct Cur { int k, t; unsigned soff; int len; };
+    auto cur_at = [&](int k, int t, const Geo &g) __attribute__((always_inline)) {
+        Cur c;
+        c.k = k; c.t = t; c.len = g.len;
+        c.soff = (g.base + (unsigned)(tap_shift(t) * d.qstride)) * (unsigned)(NC * 4);
+        return c;
+    };
+    auto cur_first = [&](int k) __attribute__((always_inline)) {
+        const Geo g = geo(b0 + k * nblk);
+        int t = 0;
+        while (!tap_valid(g, t)) ++t;           // the centre tap is always valid
+        return cur_at(k, t, g);
+    };
+    auto cur_next = [&](const Cur &c) __attribute__((always_inline)) {
+        if (c.len == 0) return c;
+        const Geo g = geo(b0 + c.k * nblk);
+        int nt = c.t + 1;
+        while (nt < 3 && !tap_valid(g, nt)) ++nt;
+        if (nt < 3) return cur_at(c.k, nt, g);
+        if (c.k + 1 < K) return cur_first(c.k + 1);
+        Cur e = c;
+        e.len = 0; e.soff = 0;
+        return e;
+    };
+
+    // this thread's share of an operand tile: float4 number c4 of rows r0 + p * RPP
+    const int r0 = tid / F4R, c4 = tid % F4R;
+    const unsigned vo0 = (unsigned)(r0 * d.pstride * NC + c4 * 4) * 4u;
+    const unsigned vstep = (unsigned)(RPP * d.pstride * NC) * 4u;
+    const int wbase = r0 * PITCH + (c4 & 1) * 8, cw = c4 >> 1;
+    f32x4 stg[PASSES];
+    auto load_pass = [&](int p, const Cur &c) __attribute__((always_inline)) {
+        const unsigned vo = (r0 + p * RPP < c.len) ? vo0 + (unsigned)p * vstep : ERF_OOB;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)vo, (int)c.soff, 0);
+        stg[p] = __builtin_bit_cast(f32x4, v);
+    };
+    auto plane_off = [&](int p) __attribute__((always_inline)) {
+        const int r = p * RPP + r0;
+        return p * RPP * PITCH + wbase + ((cw ^ line_swz<NC>(r)) << 4);
+    };
+
+    // LDS-DMA of the residual tile (fp32, 16-byte chunks of a row XOR-swizzled by the row index)
+    auto issue_res = [&](const Geo &g) __attribute__((always_inline)) {
+        const float *res = reinterpret_cast<const float *>(d.epi1.res);
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int r = p * RPP + r0;
+            const int c = c4 ^ (r & (F4R - 1));
+            const int rr = r < g.len ? r : g.len - 1;
+            const float *gp = res + ((size_t)(g.base + (unsigned)(rr * d.pstride)) * NC + c * 4);
+            lds_dma16(gp, lds0 + OFF_RES + (p * 256 + wave * 64) * 16);
+        }
+    };
+
+    // ---- prologue: first operand tile into registers, weights, constants, first tile split into LDS
+    Cur c1 = cur_first(0);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) load_pass(p, c1);
+    c1 = cur_next(c1);
+
+    bf16x8 w[3][3][KS];         // [plane][tap][k-step]
+#pragma unroll
+    for (int P = 0; P < 3; ++P)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                w[P][t][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + P * PL + ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8);
+
+    for (int c = tid; c < NC; c += 256) {
+        float sc, sh;
+        epi_channel_affine(d.epi1, c, sc, sh);
+        cst[c] = sc; cst[NC + c] = sh;
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const f32x4 x = stg[p];
+        const f32x2 xa = f32x2{x[0], x[1]}, xb = f32x2{x[2], x[3]};
+        const unsigned ha = x3_cvt2(xa), hb = x3_cvt2(xb);
+        const f32x2 ra = x3_sub_bf16x2(xa, ha), rb = x3_sub_bf16x2(xb, hb);
+        const unsigned ma = x3_cvt2(ra), mb = x3_cvt2(rb);
+        const unsigned la = x3_cvt2(x3_sub_bf16x2(ra, ma)), lb = x3_cvt2(x3_sub_bf16x2(rb, mb));
+        unsigned char *dst = lds + OFF_TAP + plane_off(p);
+        *reinterpret_cast<u32x2 *>(dst) = u32x2{ha, hb};
+        *reinterpret_cast<u32x2 *>(dst + TP) = u32x2{ma, mb};
+        *reinterpret_cast<u32x2 *>(dst + 2 * TP) = u32x2{la, lb};
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) load_pass(p, c1);     // second tile of the stream (dead: zeros)
+    Cur c2 = cur_next(c1);
+    __syncthreads();
+
+    f32x16 acc[WM];
+    auto clear_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    };
+
+    // One tap: 6 x WM MFMAs per k-step (terms lh hl mm mh hm hh per pixel tile), one piece of side
+    // work behind each: the fragment reads of the next k-step, then the split of PER float4 of the
+    // staged tile into the other TAP buffer and the load of the same float4 of the tile after it.
+    auto run_tap = [&](auto tap_c, int seq, const Cur &nx) __attribute__((always_inline)) {
+        constexpr int TAP = decltype(tap_c)::value;
+        const unsigned char *tb = lds + OFF_TAP + (seq & 1) * T3;
+        unsigned char *nb = lds + OFF_TAP + ((seq + 1) & 1) * T3;
+        const unsigned char *rowp[WM];
+        unsigned x4[WM];
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+            const int px = (wp * WM + a) * 32 + l31;
+            rowp[a] = tb + px * PITCH;
+            x4[a] = (unsigned)((line_swz<NC>(px) ^ h) << 4);
+        }
+        bf16x8 xf[2][3][WM];
+#pragma unroll
+        for (int P = 0; P < 3; ++P)
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+                xf[0][P][a] = *reinterpret_cast<const bf16x8 *>(rowp[a] + P * TP + x4[a]);
+        f32x2 ra, rb;
+        unsigned ha = 0, hb = 0, ma = 0, mb = 0, la = 0, lb = 0;
+        // piece q (0..5) of the conversion of staged float4 p
+        auto piece = [&](int p, int q) __attribute__((always_inline)) {
+            if (q == 0) {
+                const f32x2 xa = f32x2{stg[p][0], stg[p][1]};
+                ha = x3_cvt2(xa);
+                ra = x3_sub_bf16x2(xa, ha);
+            } else if (q == 1) {
+                ma = x3_cvt2(ra);
+                la = x3_cvt2(x3_sub_bf16x2(ra, ma));
+            } else if (q == 2) {
+                const f32x2 xb = f32x2{stg[p][2], stg[p][3]};
+                hb = x3_cvt2(xb);
+                rb = x3_sub_bf16x2(xb, hb);
+            } else if (q == 3) {
+                mb = x3_cvt2(rb);
+                lb = x3_cvt2(x3_sub_bf16x2(rb, mb));
+            } else if (q == 4) {
+                unsigned char *dst = nb + plane_off(p);
+                *reinterpret_cast<u32x2 *>(dst) = u32x2{ha, hb};
+                *reinterpret_cast<u32x2 *>(dst + TP) = u32x2{ma, mb};
+                *reinterpret_cast<u32x2 *>(dst + 2 * TP) = u32x2{la, lb};
+            } else {
+                load_pass(p, nx);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int j = 0; j < 6 * WM; ++j) {
+                const int a = j % WM, term = j / WM;
+                // (weight plane, operand plane): small terms first
+                const int pw = term == 0 ? 2 : (term == 1 || term == 4 || term == 5 ? 0 : 1);
+                const int px = term == 1 ? 2 : (term == 0 || term == 3 || term == 5 ? 0 : 1);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[pw][TAP][s], xf[s & 1][px][a], acc[a], 0, 0, 0);
+                if (j < 3 * WM) {
+                    if (s + 1 < KS) {
+                        const int P = j / WM, fa = j % WM;
+                        xf[(s + 1) & 1][P][fa] =
+                            *reinterpret_cast<const bf16x8 *>(rowp[fa] + P * TP + ((unsigned)((s + 1) << 5) ^ x4[fa]));
+                    }
+                    if (PER == 2) piece(2 * s, j);
+                } else {
+                    piece(PER == 2 ? 2 * s + 1 : s, j - 3 * WM);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // accumulators -> fp32 tile in LDS: v = acc*sc + sh [+ residual tile, in place] -> [relu]
+    auto store_acc_t = [&](auto relu_t, auto scale_t, auto res_t) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(relu_t)::value, SCALE = decltype(scale_t)::value, RES = decltype(res_t)::value;
+        f32x4 sc[4], sh[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int ch = 32 * cg + 8 * gq + 4 * h;
+            if (SCALE) sc[gq] = *reinterpret_cast<const f32x4 *>(cst + ch);
+            sh[gq] = *reinterpret_cast<const f32x4 *>(cst + NC + ch);
+        }
+#pragma unroll
+        for (int a = 0; a < WM; ++a) {
+            const int px = (wp * WM + a) * 32 + l31;
+            const int sw = px & (F4R - 1);
+            f32x4 rr[4];
+            if (RES) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    rr[gq] = *reinterpret_cast<const f32x4 *>(lds + OFF_RES + px * FPITCH + (((8 * cg + 2 * gq + h) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 v = f32x4{acc[a][4 * gq], acc[a][4 * gq + 1], acc[a][4 * gq + 2], acc[a][4 * gq + 3]};
+                if (SCALE) v = v * sc[gq] + sh[gq];
+                else v = v + sh[gq];
+                if (RES) v = v + rr[gq];
+                if (RELU) v = __builtin_elementwise_max(v, f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+                *reinterpret_cast<f32x4 *>(lds + OFF_RES + px * FPITCH + (((8 * cg + 2 * gq + h) ^ sw) << 4)) = v;
+            }
+        }
+    };
+    auto store_acc = [&]() __attribute__((always_inline)) {
+        using T1 = std::true_type;
+        using T0 = std::false_type;
+        const int key = (d.epi1.relu ? 4 : 0) | (d.epi1.bn.on ? 2 : 0) | (has_res ? 1 : 0);
+        switch (key) {          // wave-uniform
+        case 0: store_acc_t(T0{}, T0{}, T0{}); break;
+        case 1: store_acc_t(T0{}, T0{}, T1{}); break;
+        case 2: store_acc_t(T0{}, T1{}, T0{}); break;
+        case 3: store_acc_t(T0{}, T1{}, T1{}); break;
+        case 4: store_acc_t(T1{}, T0{}, T0{}); break;
+        case 5: store_acc_t(T1{}, T0{}, T1{}); break;
+        case 6: store_acc_t(T1{}, T1{}, T0{}); break;
+        default: store_acc_t(T1{}, T1{}, T1{}); break;
+        }
+    };
+    // coalesced pass over the finished fp32 tile: [mask by a global tensor] -> global store
+    auto sweep_tile = [&](const Geo &g) __attribute__((always_inline)) {
+        const float *mk = reinterpret_cast<const float *>(d.epi1.mask);
+        constexpr int B = 4;
+#pragma unroll
+        for (int p0 = 0; p0 < PASSES; p0 += B) {
+            f32x4 v[B], m[B];
+            size_t off[B];
+            bool live[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                const int p = p0 + i;
+                const int r = p * RPP + r0;
+                const int c = c4 ^ (r & (F4R - 1));
+                live[i] = r < g.len;
+                const int rr = live[i] ? r : g.len - 1;
+                off[i] = (size_t)(g.base + (unsigned)(rr * d.pstride)) * NC + c * 4;
+                v[i] = *reinterpret_cast<const f32x4 *>(lds + OFF_RES + (p * 256 + tid) * 16);
+            }
+            if (mk) {
+#pragma unroll
+                for (int i = 0; i < B; ++i) m[i] = *reinterpret_cast<const f32x4 *>(mk + off[i]);
+#pragma unroll
+                for (int i = 0; i < B; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][e] = m[i][e] > 0.0f ? v[i][e] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < B; ++i)
+                if (live[i]) *reinterpret_cast<f32x4 *>(out + off[i]) = v[i];
+        }
+    };
+
+    clear_acc();
+    int seq = 0;
+    for (int k = 0; k < K; ++k) {
+        const Geo g = geo(b0 + k * nblk);
+        if (has_res) issue_res(g);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (!tap_valid(g, t)) continue;                 // wave-uniform
+            if (t == 0) run_tap(std::integral_constant<int, 0>{}, seq, c2);
+            else if (t == 1) run_tap(std::integral_constant<int, 1>{}, seq, c2);
+            else run_tap(std::integral_constant<int, 2>{}, seq, c2);
+            c2 = cur_next(c2);
+            ++seq;
+            bool last = true;
+#pragma unroll
+            for (int u = t + 1; u < 3; ++u) last = last && !tap_valid(g, u);
+            // the residual tile (this wave's part) has landed before the barrier that opens the epilogue
+            if (last && has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();      // next operand tile complete in LDS; this one may be overwritten
+        }
+        store_acc();
+        clear_acc();
+        lds_barrier();
+        sweep_tile(g);
+        lds_barrier();          // the fp32 tile may be refilled; the stores stay in flight
+    }
+}

@@ -577,6 +577,36 @@ def conv_pair(x, packed, b_first, b_second, first_axis, dil_first=1, dil_second=
     return (y, mid) if keep_mid else y
 
 
+def conv_line_pack_split(w):
+    """Split the [C,C,3,1] / [C,C,1,3] weights of a 1-D convolution into three bf16 planes laid out
+    as matrix fragments for :func:`conv_line_split` (erf_conv_line_pack_split)."""
+    c = w.shape[0]
+    wq = _param(w)
+    packed = torch.empty(3 * 3 * c * c, dtype=torch.bfloat16, device=wq.device)
+    with _dev_ctx(wq):
+        _lib.check(_lib.lib().erf_conv_line_pack_split(_p(wq), c, _p(packed), _stream(wq)))
+    return packed
+
+
+def conv_line_split(x, packed, bias, axis, dil=1, relu=True, residual=None, mask=None):
+    """One 3-tap convolution of non_bottleneck_1d.forward (reference train/erfnet_blocks.py:57-66) on
+    fp32 tensors, computed with split-bf16 operands on the bf16 matrix pipe; inference only (no
+    autograd graph).  axis 0: kernel (3,1); 1: kernel (1,3).
+    ``y = where(mask > 0, act(conv(x) + bias [+ residual]), 0)``."""
+    x = _nhwc(x.detach())
+    if x.dtype != torch.float32:
+        raise TypeError("conv_line_split takes fp32 tensors")
+    n, c, h, wd = x.shape
+    y = torch.empty_like(x)
+    res = None if residual is None else _nhwc(residual.detach())
+    mk = None if mask is None else _nhwc(mask.detach())
+    with _dev_ctx(x):
+        _lib.check(_lib.lib().erf_conv_line_forward_split(_p(x), _p(packed), _p(_param(bias)), int(axis), int(dil),
+                                                          int(bool(relu)), _p(res), _p(mk), _p(y), n, c, h, wd,
+                                                          _stream(x)))
+    return y
+
+
 # ------------------------------------------------------------------------------ UpsamplerBlock
 class _Upsampler(torch.autograd.Function):
     @staticmethod

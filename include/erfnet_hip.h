@@ -69,6 +69,12 @@ unsigned long long erf_launch_count(void);
 /* ERF_OPT_LINE2 (default 1; ERFNET_NO_LINE2=1): bf16 conv pairs on the eight-wave kernel whose wave
  * groups work on consecutive tiles (line2_bf16_kernel); off = the four-wave kernel; same results. */
 #define ERF_OPT_LINE2 5
+/* ERF_OPT_SPLIT_BF16 (default 0; ERFNET_X3=1): the fp32 64/128-channel 1-D convolutions on the bf16
+ * matrix pipe, each fp32 operand split into three bf16 terms and six of the nine partial products
+ * accumulated in fp32 (line_x3_kernel): fp32 storage and fp32-level accuracy (the dropped terms are
+ * below 2^-24 of a product), 2.7x the fp32 matrix rate.  Results differ from the fp32-MFMA kernels
+ * by fp32 rounding. */
+#define ERF_OPT_SPLIT_BF16 6
 int erf_set_option(int option, int value);
 
 /* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block
@@ -331,6 +337,16 @@ int erf_conv_pair_forward_bf16(const void *x, const void *packed, const float *b
                                const float *b_second, int first_axis, int dil_first, int dil_second,
                                int relu_first, int relu_second, const void *residual, void *mid,
                                void *y, int N, int C, int H, int W, void *stream);
+/* ---- One 3-tap 1-D convolution C -> C (C = 64 / 128) of a non_bottleneck_1d (train/erfnet_blocks.py:
+ *      57-66) on fp32 tensors, computed on the bf16 matrix pipe with split operands (see
+ *      ERF_OPT_SPLIT_BF16) — the kernel the fp32 training step spends most of its time in.
+ * y = [mask > 0 ?] act(conv(x) + bias [+ residual]) [: 0];  axis 0 = kernel (3,1) along H, 1 = kernel
+ * (1,3) along W.  packed: 3 * 3*C*C bf16 from erf_conv_line_pack_split (w in torch's layout [C][C][3]).
+ * x, y, residual, mask: NHWC, 16-byte aligned, y distinct from x. */
+int erf_conv_line_pack_split(const float *w, int C, void *packed, void *stream);
+int erf_conv_line_forward_split(const float *x, const void *packed, const float *bias, int axis, int dil,
+                                int relu, const float *residual, const float *mask, float *y, int N,
+                                int C, int H, int W, void *stream);
 int erf_upsampler_forward_bf16(const void *x, const float *w, const float *b, const erf_bn_t *bn,
                                void *y, void *pre, int N, int Cin, int H, int W, int Cout, void *ws,
                                size_t ws_bytes, void *stream);

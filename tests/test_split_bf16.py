@@ -1,0 +1,93 @@
+"""GPU parity tests of the split-bf16 path for fp32 tensors (ERF_OPT_SPLIT_BF16): the 64/128-channel
+1-D convolutions and their weight gradients computed on the bf16 matrix pipe from fp32 operands
+split into three bf16 terms.  The claim tested is fp32-level accuracy: the error against a float64
+evaluation must not exceed that of the fp32-MFMA kernels by more than a small factor, and the
+oracle comparisons of the fp32 path must pass unchanged with the option on."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import test_hip_parity as thp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def split_on():
+    from erfnet_pytorch_amd import _lib
+    prev = _lib.set_option(_lib.OPT_SPLIT_BF16, 1)
+    yield
+    _lib.set_option(_lib.OPT_SPLIT_BF16, prev)
+
+
+@pytest.mark.parametrize("C_,dil,N,H,W", [(64, 4, 2, 20, 24), (128, 16, 1, 20, 24), (128, 2, 2, 70, 136),
+                                          (64, 1, 1, 130, 260)])
+def test_nb1d_c_abi_against_oracle_split(split_on, C_, dil, N, H, W):
+    """erf_nb1d_forward / erf_nb1d_backward vs the CPU oracle (same masks on both sides), with the
+    1-D convolutions and weight gradients on the split-bf16 kernels; includes shapes with several
+    tiles per block and ragged line segments."""
+    thp.test_nb1d_c_abi_against_oracle(C_, dil, N, H, W)
+
+
+@pytest.mark.parametrize("C_,dil,N,H,W,mode,drop", [(64, 2, 2, 20, 24, 2, False), (128, 4, 2, 12, 20, 2, True),
+                                                    (64, 8, 1, 20, 24, 1, True)])
+def test_nb1d_c_abi_batchnorm_against_oracle_split(split_on, C_, dil, N, H, W, mode, drop):
+    thp.test_nb1d_c_abi_batchnorm_against_oracle(C_, dil, N, H, W, mode, drop)
+
+
+@pytest.mark.parametrize("C_,axis,dil,N,H,W", [(128, 0, 1, 2, 40, 200), (128, 1, 8, 3, 100, 90), (64, 0, 2, 1, 33, 300),
+                                               (64, 1, 1, 2, 260, 70), (128, 1, 16, 1, 9, 17)])
+def test_conv_line_split_against_float64(C_, axis, dil, N, H, W):
+    """erf_conv_line_forward_split (one convolution, residual + ReLU + mask epilogue) against torch's
+    float64 convolution on the CPU; tolerance = a few fp32 roundings of the accumulated sum."""
+    from erfnet_pytorch_amd import functional as hipf
+    g = torch.Generator().manual_seed(C_ + 7 * axis + dil)
+    x = torch.randn(N, C_, H, W, generator=g)
+    ks = (3, 1) if axis == 0 else (1, 3)
+    w = torch.randn(C_, C_, *ks, generator=g) * 0.05
+    b = torch.randn(C_, generator=g) * 0.1
+    res = torch.randn(N, C_, H, W, generator=g)
+    mask = torch.randn(N, C_, H, W, generator=g)
+    pad = (dil, 0) if axis == 0 else (0, dil)
+    dl = (dil, 1) if axis == 0 else (1, dil)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=pad, dilation=dl) + res.double())
+    ref = torch.where(mask.double() > 0, ref, torch.zeros_like(ref))
+    packed = hipf.conv_line_pack_split(w.to(DEV))
+    y = hipf.conv_line_split(x.to(DEV), packed, b.to(DEV), axis, dil, True, residual=res.to(DEV), mask=mask.to(DEV))
+    err = (y.double().cpu() - ref).abs()
+    scale = ref.abs().max().item()
+    assert err.max().item() <= 4e-6 * scale, (err.max().item(), scale)
+    # and without the optional tensors
+    ref2 = F.conv2d(x.double(), w.double(), b.double(), padding=pad, dilation=dl)
+    y2 = hipf.conv_line_split(x.to(DEV), packed, b.to(DEV), axis, dil, False)
+    err2 = (y2.double().cpu() - ref2).abs()
+    assert err2.max().item() <= 4e-6 * ref2.abs().max().item()
+
+
+def test_split_path_is_as_accurate_as_fp32_mfma():
+    """Whole block forward at a training shape: rms error against float64 of the split path within
+    1.5x of the fp32-MFMA path's, and the two paths really are different kernels."""
+    from erfnet_pytorch_amd import _lib, erfnet_blocks
+    torch.manual_seed(5)
+    blk = erfnet_blocks.non_bottleneck_1d(128, 0.0, 2).to(DEV).eval()
+    x = torch.randn(2, 128, 64, 128, device=DEV).relu_().contiguous(memory_format=torch.channels_last)
+    xd = x.double().cpu()
+    o = xd
+    for i, name in enumerate(("conv3x1_1", "conv1x3_1", "conv3x1_2", "conv1x3_2")):
+        m = getattr(blk, name)
+        o = F.conv2d(o, m.weight.double().cpu(), m.bias.double().cpu(), padding=m.padding, dilation=m.dilation)
+        o = F.relu(o + xd) if i == 3 else F.relu(o)
+    ys = []
+    for opt in (0, 1):
+        prev = _lib.set_option(_lib.OPT_SPLIT_BF16, opt)
+        try:
+            with torch.no_grad():
+                ys.append(blk(x).double().cpu())
+        finally:
+            _lib.set_option(_lib.OPT_SPLIT_BF16, prev)
+    rms = [(y - o).pow(2).mean().sqrt().item() for y in ys]
+    assert not torch.equal(ys[0], ys[1])
+    assert rms[1] <= 1.5 * rms[0] + 1e-9, rms
+    assert (ys[1] - o).abs().max().item() <= 2e-6 * o.abs().max().item()
