@@ -31,10 +31,10 @@ __device__ __forceinline__ unsigned x3_cvt2(f32x2 v)
 }
 
 template <int NC, int BM>
-__global__ __launch_bounds__(256, 1) void line_x3_kernel(const LineDesc d)
+__global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel(const LineDesc d)
 {
     constexpr int GC = NC / 32, GP = 4 / GC, WM = BM / (32 * GP);
-    static_assert(WM == 2 && WM * GP * 32 == BM, "tile shape: two 32-pixel MFMA tiles per wave");
+    static_assert((WM == 1 || WM == 2) && WM * GP * 32 == BM, "tile shape: one or two 32-pixel MFMA tiles per wave");
     constexpr int KS = NC / 16;                 // MFMA k-steps per tap
     constexpr int PITCH = NC * 2;               // bytes per pixel row of a bf16 plane
     constexpr int TP = BM * PITCH, T3 = 3 * TP; // one plane, one operand tile (three planes)
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256, 1) void line_x3_kernel(const LineDesc d)
     constexpr int PASSES = BM / RPP;            // float4 per thread and tile
     static_assert(PASSES % KS == 0 && PASSES / KS <= 2, "conversions per k-step");
     constexpr int PER = PASSES / KS;
+    static_assert(PER <= WM || PER == WM, "six pieces per conversion over 6 * WM MFMA slots");
     constexpr int OFF_TAP = 0, OFF_RES = 2 * T3, OFF_CST = OFF_RES + TF;
     static_assert(OFF_CST + 2 * NC * 4 <= 160 * 1024, "LDS budget");
     constexpr size_t PL = (size_t)3 * NC * NC;  // elements per weight plane
@@ -243,16 +244,14 @@ __global__ __launch_bounds__(256, 1) void line_x3_kernel(const LineDesc d)
                 const int pw = term == 0 ? 2 : (term == 1 || term == 4 || term == 5 ? 0 : 1);
                 const int px = term == 1 ? 2 : (term == 0 || term == 3 || term == 5 ? 0 : 1);
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[pw][TAP][s], xf[s & 1][px][a], acc[a], 0, 0, 0);
-                if (j < 3 * WM) {
-                    if (s + 1 < KS) {
-                        const int P = j / WM, fa = j % WM;
-                        xf[(s + 1) & 1][P][fa] =
-                            *reinterpret_cast<const bf16x8 *>(rowp[fa] + P * TP + ((unsigned)((s + 1) << 5) ^ x4[fa]));
-                    }
-                    if (PER == 2) piece(2 * s, j);
-                } else {
-                    piece(PER == 2 ? 2 * s + 1 : s, j - 3 * WM);
+                if (j < 3 * WM && s + 1 < KS) {
+                    const int P = j / WM, fa = j % WM;
+                    xf[(s + 1) & 1][P][fa] =
+                        *reinterpret_cast<const bf16x8 *>(rowp[fa] + P * TP + ((unsigned)((s + 1) << 5) ^ x4[fa]));
                 }
+                // 6 * PER conversion pieces over the 6 * WM slots: one per slot, or the second half
+                if (PER == WM) piece(PER * s + j / 6, j % 6);
+                else if (j >= 3 * WM) piece(s, j - 3 * WM);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
