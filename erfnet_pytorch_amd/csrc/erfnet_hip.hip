@@ -58,8 +58,9 @@ Switch g_sw_pair("ERFNET_NO_PAIR"), g_sw_wgrad_line("ERFNET_NO_WGRAD_LINE"), g_s
 Switch g_sw_pair16("ERFNET_PAIR16", 0);
 std::atomic<int> g_line2{1};        // ERF_OPT_LINE2
 // fp32 64 / 128-channel 1-D convolutions on the bf16 matrix pipe, operands split in three bf16 terms
-// (line_x3_kernel); ERFNET_X3=1 or ERF_OPT_SPLIT_BF16 turns it on
-Switch g_sw_x3("ERFNET_X3", 0);
+// (line_x3_kernel, wgrad_line_x3_kernel): fp32 accuracy at 2.7x the fp32 matrix rate.  ERFNET_NO_X3=1
+// or ERF_OPT_SPLIT_BF16 = 0 keeps them on the fp32 MFMA kernels (pair_f32_kernel, wgrad_line_kernel)
+Switch g_sw_x3("ERFNET_NO_X3");
 
 int fail(const char *fmt, ...)
 {

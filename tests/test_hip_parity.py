@@ -655,6 +655,7 @@ def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
     res = {}
     prev = _lib.set_option(_lib.OPT_PAIR_FUSION, 1)
     prev16 = _lib.set_option(_lib.OPT_PAIR16, 1)        # (off by default: not faster yet)
+    prev_split = _lib.set_option(_lib.OPT_SPLIT_BF16, 0)    # (the split-bf16 path runs every convolution in a launch of its own)
     try:
         for on in (0, 1):
             _lib.set_option(_lib.OPT_PAIR_FUSION, on)
@@ -663,6 +664,7 @@ def test_fused_conv_pairs_bit_identical(C_, d, N, H, W, bn_mode):
     finally:
         _lib.set_option(_lib.OPT_PAIR_FUSION, prev)
         _lib.set_option(_lib.OPT_PAIR16, prev16)
+        _lib.set_option(_lib.OPT_SPLIT_BF16, prev_split)
     # without BatchNorm the forward pair and both backward pairs fuse; inference folds eval-mode
     # BatchNorm into the epilogue (pair possible); batch statistics, or a BatchNorm whose input is
     # kept for backward, sit between the two convolutions of the forward pair, never between those
@@ -1011,12 +1013,14 @@ def test_nb1d_full_size_vs_torch_fp32(C_, d, H, W):
         # rare ReLU mask flips (pre-activation within rounding of 0) perturb a 3x3x3-pixel
         # neighbourhood of dx by O(|g| |w|); everything else must agree to 1e-3 of the scale
         # (parameter gradients sum over ~50k-800k pixels, so one flip moves an element by O(1):
-        # they get a tolerance relative to the tensor's scale instead of an outlier allowance)
+        # they get a tolerance relative to the tensor's scale, and one element in 10^4 may miss it
+        # by a few flips' worth)
         if i < 2:
             gu.check_arrays(a, b, 1e-4, 1e-3, what=f"tensor{i}", scale_rtol=1e-3, outlier_frac=0.002,
                             outlier_rtol=0.5)
         else:
-            gu.check_arrays(a, b, 1e-4, 1e-3, what=f"tensor{i}", scale_rtol=5e-3)
+            gu.check_arrays(a, b, 1e-4, 1e-3, what=f"tensor{i}", scale_rtol=5e-3, outlier_frac=1e-4,
+                            outlier_rtol=2e-2)
 
 
 def test_full_size_properties_batch6():
