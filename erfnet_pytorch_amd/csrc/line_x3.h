@@ -23,7 +23,8 @@
 // x - (bf16 pair as fp32)
 __device__ __forceinline__ f32x2 x3_sub_bf16x2(f32x2 x, unsigned p)
 {
-    return f32x2{x[0] - __builtin_bit_cast(float, p << 16), x[1] - __builtin_bit_cast(float, p & 0xffff0000u)};
+    const f32x2 b = f32x2{__builtin_bit_cast(float, p << 16), __builtin_bit_cast(float, p & 0xffff0000u)};
+    return x - b;           // one packed subtraction
 }
 __device__ __forceinline__ unsigned x3_cvt2(f32x2 v)
 {
@@ -65,6 +66,17 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
     const bool has_res = d.epi1.res != nullptr;
     const int K = b0 < ntiles ? (ntiles - b0 + nblk - 1) / nblk : 0;        // tiles of this block
     if (K == 0) return;
+#ifdef ERF_LINE_STAMPS
+    int stamp_i = 0;
+#define X3_STAMP()                                                                                 \
+    do {                                                                                           \
+        if (d.stamps && tid == 0 && stamp_i < 48)                                                  \
+            d.stamps[(size_t)blockIdx.x * 48 + stamp_i++] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+#else
+#define X3_STAMP() do {} while (0)
+#endif
+    X3_STAMP();     // 0: start
 
     const float *in = reinterpret_cast<const float *>(d.in);
     float *out = reinterpret_cast<float *>(d.out);
@@ -86,26 +98,29 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
         return (unsigned)(g.q + tap_shift(t)) < (unsigned)d.lines_per_img;
     };
     // The block consumes a STREAM of operand tiles: the valid taps of its first line tile, then of
-    // its second, ...  A cursor names one of them (dead = past the end: loads nothing).
-    struct Cur { int k, t; unsigned soff; int len; };
-    auto cur_at = [&](int k, int t, const Geo &g) __attribute__((always_inline)) {
+    // its second, ...  A cursor names one of them (dead = past the end: loads nothing).  The block's
+    // first tile takes its taps in the order 1, 0, 2: the centre tap is valid on every line, so the
+    // first tap a block runs is always tap 1 (its weights are the only ones the prologue loads).
+    struct Cur { int k, i; unsigned soff; int len; };       // i = position in the tile's tap order
+    auto tap_at = [&](int k, int i) __attribute__((always_inline)) { return k == 0 ? (i == 0 ? 1 : (i == 1 ? 0 : 2)) : i; };
+    auto cur_at = [&](int k, int i, const Geo &g) __attribute__((always_inline)) {
         Cur c;
-        c.k = k; c.t = t; c.len = g.len;
-        c.soff = (g.base + (unsigned)(tap_shift(t) * d.qstride)) * (unsigned)(NC * 4);
+        c.k = k; c.i = i; c.len = g.len;
+        c.soff = (g.base + (unsigned)(tap_shift(tap_at(k, i)) * d.qstride)) * (unsigned)(NC * 4);
         return c;
     };
     auto cur_first = [&](int k) __attribute__((always_inline)) {
         const Geo g = geo(b0 + k * nblk);
-        int t = 0;
-        while (!tap_valid(g, t)) ++t;           // the centre tap is always valid
-        return cur_at(k, t, g);
+        int i = 0;
+        while (!tap_valid(g, tap_at(k, i))) ++i;    // the centre tap is always valid
+        return cur_at(k, i, g);
     };
     auto cur_next = [&](const Cur &c) __attribute__((always_inline)) {
         if (c.len == 0) return c;
         const Geo g = geo(b0 + c.k * nblk);
-        int nt = c.t + 1;
-        while (nt < 3 && !tap_valid(g, nt)) ++nt;
-        if (nt < 3) return cur_at(c.k, nt, g);
+        int ni = c.i + 1;
+        while (ni < 3 && !tap_valid(g, tap_at(c.k, ni))) ++ni;
+        if (ni < 3) return cur_at(c.k, ni, g);
         if (c.k + 1 < K) return cur_first(c.k + 1);
         Cur e = c;
         e.len = 0; e.soff = 0;
@@ -147,14 +162,18 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
     for (int p = 0; p < PASSES; ++p) load_pass(p, c1);
     c1 = cur_next(c1);
 
+    // A CU's 288 KB of weight fragments need ~5 k cycles of its vector-memory path: only the weights
+    // of the block's first tap are loaded here; those of the other two taps are requested piecewise
+    // behind the MFMAs of that first tap (run_tap, FIRST) and have arrived when it ends.
     bf16x8 w[3][3][KS];         // [plane][tap][k-step]
+    auto load_w = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-    for (int P = 0; P < 3; ++P)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int P = 0; P < 3; ++P)
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 w[P][t][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + P * PL + ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8);
+    };
+    load_w(1);
 
     for (int c = tid; c < NC; c += 256) {
         float sc, sh;
@@ -177,7 +196,9 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) load_pass(p, c1);     // second tile of the stream (dead: zeros)
     Cur c2 = cur_next(c1);
-    __syncthreads();
+    X3_STAMP();     // 1: prologue issued
+    lds_barrier();              // (orders LDS only: the weight loads stay in flight)
+    X3_STAMP();     // 2: prologue done
 
     f32x16 acc[WM];
     auto clear_acc = [&]() __attribute__((always_inline)) {
@@ -190,8 +211,11 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
     // One tap: 6 x WM MFMAs per k-step (terms lh hl mm mh hm hh per pixel tile), one piece of side
     // work behind each: the fragment reads of the next k-step, then the split of PER float4 of the
     // staged tile into the other TAP buffer and the load of the same float4 of the tile after it.
-    auto run_tap = [&](auto tap_c, int seq, const Cur &nx) __attribute__((always_inline)) {
+    auto run_tap = [&](auto tap_c, auto first_c, int seq, const Cur &nx) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tap_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;    // the block's first tap (tap 1): fetches the other taps' weights
+        static_assert(!FIRST || TAP == 1, "a block starts with the centre tap");
+        constexpr int OT1 = 0, OT2 = 2;
         const unsigned char *tb = lds + OFF_TAP + (seq & 1) * T3;
         unsigned char *nb = lds + OFF_TAP + ((seq + 1) & 1) * T3;
         const unsigned char *rowp[WM];
@@ -248,6 +272,10 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
                     const int P = j / WM, fa = j % WM;
                     xf[(s + 1) & 1][P][fa] =
                         *reinterpret_cast<const bf16x8 *>(rowp[fa] + P * TP + ((unsigned)((s + 1) << 5) ^ x4[fa]));
+                }
+                if (FIRST && j < 6) {
+                    const int P = j % 3, ot = j < 3 ? OT1 : OT2;
+                    w[P][ot][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + P * PL + ((size_t)((ot * KS + s) * GC + cg) * 64 + lane) * 8);
                 }
                 // 6 * PER conversion pieces over the 6 * WM slots: one per slot, or the second half
                 if (PER == WM) piece(PER * s + j / 6, j % 6);
@@ -338,28 +366,41 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
 
     clear_acc();
     int seq = 0;
-    for (int k = 0; k < K; ++k) {
+    auto tile_body = [&](auto first_tile_c, int k) __attribute__((always_inline)) {
+        constexpr bool FT = decltype(first_tile_c)::value;
+        using F1 = std::true_type;
+        using F0 = std::false_type;
         const Geo g = geo(b0 + k * nblk);
         if (has_res) issue_res(g);
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
+        for (int i = 0; i < 3; ++i) {
+            const int t = FT ? (i == 0 ? 1 : (i == 1 ? 0 : 2)) : i;
             if (!tap_valid(g, t)) continue;                 // wave-uniform
-            if (t == 0) run_tap(std::integral_constant<int, 0>{}, seq, c2);
-            else if (t == 1) run_tap(std::integral_constant<int, 1>{}, seq, c2);
-            else run_tap(std::integral_constant<int, 2>{}, seq, c2);
+            if (FT && i == 0) run_tap(std::integral_constant<int, 1>{}, F1{}, seq, c2);
+            else if (t == 0) run_tap(std::integral_constant<int, 0>{}, F0{}, seq, c2);
+            else if (t == 1) run_tap(std::integral_constant<int, 1>{}, F0{}, seq, c2);
+            else run_tap(std::integral_constant<int, 2>{}, F0{}, seq, c2);
             c2 = cur_next(c2);
             ++seq;
+            X3_STAMP();     // tap MFMAs issued
             bool last = true;
 #pragma unroll
-            for (int u = t + 1; u < 3; ++u) last = last && !tap_valid(g, u);
+            for (int u = i + 1; u < 3; ++u) last = last && !tap_valid(g, FT ? (u == 1 ? 0 : 2) : u);
             // the residual tile (this wave's part) has landed before the barrier that opens the epilogue
             if (last && has_res) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             lds_barrier();      // next operand tile complete in LDS; this one may be overwritten
+            X3_STAMP();     // tap barrier passed
         }
         store_acc();
         clear_acc();
+        X3_STAMP();         // accumulators in the fp32 tile
         lds_barrier();
+        X3_STAMP();
         sweep_tile(g);
+        X3_STAMP();         // output pass issued
         lds_barrier();          // the fp32 tile may be refilled; the stores stay in flight
-    }
+        X3_STAMP();
+    };
+    tile_body(std::true_type{}, 0);
+    for (int k = 1; k < K; ++k) tile_body(std::false_type{}, k);
 }
