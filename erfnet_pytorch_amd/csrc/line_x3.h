@@ -331,28 +331,32 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
         default: store_acc_t(T1{}, T1{}, T1{}); break;
         }
     };
-    // coalesced pass over the finished fp32 tile: [mask by a global tensor] -> global store
+    // coalesced pass over the finished fp32 tile: [mask by a global tensor] -> global store.  Buffer
+    // accesses with the tile's base as the scalar offset: rows beyond the line present an out-of-range
+    // offset (loads return zero, stores are dropped), no 64-bit address arithmetic.
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, (unsigned)((size_t)d.N * d.img_pixels * NC * 4));
+    const __amdgpu_buffer_rsrc_t rmk = make_rsrc(d.epi1.mask, (unsigned)((size_t)d.N * d.img_pixels * NC * 4));
+    const unsigned so0 = (unsigned)(r0 * d.pstride * NC) * 4u;
     auto sweep_tile = [&](const Geo &g) __attribute__((always_inline)) {
-        const float *mk = reinterpret_cast<const float *>(d.epi1.mask);
+        const bool masked = d.epi1.mask != nullptr;
+        const unsigned soff = g.base * (unsigned)(NC * 4);
         constexpr int B = 4;
 #pragma unroll
         for (int p0 = 0; p0 < PASSES; p0 += B) {
             f32x4 v[B], m[B];
-            size_t off[B];
-            bool live[B];
+            unsigned vo[B];
 #pragma unroll
             for (int i = 0; i < B; ++i) {
                 const int p = p0 + i;
                 const int r = p * RPP + r0;
                 const int c = c4 ^ (r & (F4R - 1));
-                live[i] = r < g.len;
-                const int rr = live[i] ? r : g.len - 1;
-                off[i] = (size_t)(g.base + (unsigned)(rr * d.pstride)) * NC + c * 4;
+                vo[i] = r < g.len ? so0 + (unsigned)p * vstep + (unsigned)(c * 16) : ERF_OOB;
                 v[i] = *reinterpret_cast<const f32x4 *>(lds + OFF_RES + (p * 256 + tid) * 16);
             }
-            if (mk) {
+            if (masked) {
 #pragma unroll
-                for (int i = 0; i < B; ++i) m[i] = *reinterpret_cast<const f32x4 *>(mk + off[i]);
+                for (int i = 0; i < B; ++i)
+                    m[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)vo[i], (int)soff, 0));
 #pragma unroll
                 for (int i = 0; i < B; ++i)
 #pragma unroll
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
             }
 #pragma unroll
             for (int i = 0; i < B; ++i)
-                if (live[i]) *reinterpret_cast<f32x4 *>(out + off[i]) = v[i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), rout, (int)vo[i], (int)soff, 0);
         }
     };
 

@@ -1,9 +1,10 @@
 #!/bin/bash
-# PMC passes (one rocprofv3 run per counter set) over the fused-pair micro-benchmark.
-# usage: scripts/pmc_pair.sh <tag> <micro_pair args...>
+# PMC passes (one rocprofv3 run per counter set) over a micro-benchmark script.
+# usage: scripts/pmc_any.sh <tag> <script.py> <args...>   -> gpurun_out/pmc_<tag>/
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 tag=$1; shift
+script=$1; shift
 i=0
 for set in \
   "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS" \
@@ -11,6 +12,6 @@ for set in \
   "FETCH_SIZE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -o pass$i -- python scripts/micro_pair.py "$@" > gpurun_out/pmc_${tag}_pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/pmc_${tag}_pass$i.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -o pass$i -- python3 $script "$@" > gpurun_out/pmc_${tag}_pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 gpurun_out/pmc_${tag}_pass$i.log; exit 1; }
 done
 echo done $tag
