@@ -870,8 +870,18 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     // fp32 tensors on the bf16 matrix pipe (split operands): one block per CU; at 64 channels the
     // block's two wave groups write a slab each
     const bool x3 = !dd[0].dt && g_sw_x3.on();
-    const int kgroups = x3 && NC == 64 ? 2 : 1;
-    const int slots = (NC == 128 || x3) ? 256 : 768;
+    // 64 channels, dilation <= 4 (every 64-channel block of the network): a 72-row X tile, two
+    // 256-thread blocks per CU (independent blocks fill each other's staging phases)
+    int maxdil = 0;
+    for (int i = 0; i < n; ++i) {
+        const int dl = dd[i].tdw[0] == 0 && dd[i].tdw[2] == 0 ? dd[i].tdh[2] : dd[i].tdw[2];
+        maxdil = dl > maxdil ? dl : maxdil;
+    }
+    static int no_small = -1;
+    if (no_small < 0) { const char *e = getenv("ERFNET_X3_WGRAD_XR96"); no_small = (e && atoi(e)) ? 1 : 0; }
+    const bool x3_small = x3 && NC == 64 && maxdil <= 4 && !no_small;
+    const int kgroups = x3 && NC == 64 && !x3_small ? 2 : 1;
+    const int slots = x3_small ? 512 : ((NC == 128 || x3) ? 256 : 768);
     const size_t slab = (size_t)3 * NC * NC + 3 * NC;
     WgradLineBatch wb;
     memset(&wb, 0, sizeof(wb));
@@ -904,6 +914,7 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     dim3 grid((unsigned)max_split, jtiles, n);
     if (x3) {
         if (NC == 128) wgrad_line_x3_kernel<128, 1, 2, 4, 2, 1, 1><<<grid, 512, 0, st>>>(wb);
+        else if (x3_small) wgrad_line_x3_kernel<64, 1, 1, 2, 2, 1, 2, 72><<<grid, 256, 0, st>>>(wb);
         else wgrad_line_x3_kernel<64, 1, 1, 2, 2, 2, 1><<<grid, 512, 0, st>>>(wb);
     } else if (dd[0].dt) {         // bf16 tensors: bf16 MFMA, fragments through the transposing LDS read
         if (NC == 128) wgrad_line_bf16_kernel<128, 1, 2, 4, 2, 1><<<grid, 512, 0, st>>>(wb);

@@ -173,18 +173,20 @@ __global__ __launch_bounds__(GI *GJ * 64, MINB) void wgrad_line_bf16_kernel(cons
 //   x g ~= xh gh + xh gm + xm gh + xm gm + xh gl + xl gh        (the rest is below 2^-24 |x g|)
 // KG wave groups share a block's tiles and split the k-steps (positions) of every segment between
 // them; each group owns a partial slab (slab index blockIdx.x * KG + group), so no sum crosses waves.
-template <int NC, int IB, int JB, int GI, int GJ, int KG, int MINB>
+// XR = rows of the X tile (64 positions + the dilation on both sides, at most XR - 64): 96 serves every
+// dilation up to 16; 72 (dilations up to 4) lets two 64-channel blocks share a CU.
+template <int NC, int IB, int JB, int GI, int GJ, int KG, int MINB, int XR = 96>
 __global__ __launch_bounds__(GI *GJ *KG * 64, MINB) void wgrad_line_x3_kernel(const WgradLineBatch batch)
 {
     const WgradLineDesc &d = batch.d[blockIdx.z];
-    constexpr int L = 64, XR = 96, NT = GI * GJ * KG * 64;
+    constexpr int L = 64, NT = GI * GJ * KG * 64;
     static_assert(GI * IB * 32 == NC && GJ * JB * 32 == NC && (4 % KG) == 0, "tile shape");
     constexpr int Q = NC / 4;                               // float4 per row
     constexpr int PITCH = NC * 2 + 64;                      // bytes per row of a bf16 plane
     constexpr int XSZ = XR * PITCH, GSZ = L * PITCH;
-    constexpr int XP = XR * Q / NT, GP = L * Q / NT;
-    static_assert(XR * Q % NT == 0 && L * Q % NT == 0, "whole passes");
-    static_assert(3 * (XSZ + GSZ) <= 160 * 1024, "LDS budget");
+    constexpr int XP = (XR * Q + NT - 1) / NT, GP = L * Q / NT;
+    static_assert(L * Q % NT == 0, "whole passes");
+    static_assert(3 * (XSZ + GSZ) * MINB <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char Xs[3 * XSZ];
     __shared__ __attribute__((aligned(16))) unsigned char Gs[3 * GSZ];
 
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(GI *GJ *KG * 64, MINB) void wgrad_line_x3_kernel(co
             const int r = slot / Q, c = (slot % Q) * 4;
             const int q = q0 - dil + r;
             unsigned off = (base + (unsigned)(q * d.pstride)) * NC + c;
-            off |= (unsigned)(((xrows - 1 - r) | q | (d.Len - 1 - q)) >> 31) & ERF_OOB;
+            off |= (unsigned)(((xrows - 1 - r) | q | (d.Len - 1 - q)) >> 31) & ERF_OOB;      // (also rows >= XR)
             xreg[i] = Act<float>::load4(r_x, off);
         }
 #pragma unroll
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(GI *GJ *KG * 64, MINB) void wgrad_line_x3_kernel(co
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int slot = tid + i * NT;
-            split_store(Xs + (slot / Q) * PITCH + (slot % Q) * 8, XSZ, xreg[i]);
+            if (XR * Q % NT == 0 || slot < XR * Q) split_store(Xs + (slot / Q) * PITCH + (slot % Q) * 8, XSZ, xreg[i]);
         }
 #pragma unroll
         for (int i = 0; i < GP; ++i) {
