@@ -12,6 +12,7 @@
 #include "igemm_bf16.h"
 #include "wgrad_line.h"
 #include "wgrad_line_bf16.h"
+#include "wgrad_mm.h"
 #include "loss_kernels.h"
 #include "metric_kernels.h"
 
@@ -1021,6 +1022,18 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
         wb.d[i] = e;
     }
     dim3 grid((unsigned)nsplit, tiles, n);
+    // bf16 tensors, tiles of 64 / 128 channels: bf16 MFMA; ERFNET_NO_WGRAD_MM=1 keeps them on the fp32
+    // MFMA (experiments)
+    static int no_mm = -1;
+    if (no_mm < 0) { const char *e = getenv("ERFNET_NO_WGRAD_MM"); no_mm = (e && atoi(e)) ? 1 : 0; }
+    if (cfg <= 3 && !no_mm && d.dt) {
+        if (cfg == 0) wgrad_mm_kernel<2, 2, 2, 2><<<grid, 256, 0, st>>>(wb);
+        else if (cfg == 1) wgrad_mm_kernel<2, 1, 2, 2><<<grid, 256, 0, st>>>(wb);
+        else if (cfg == 2) wgrad_mm_kernel<1, 2, 2, 2><<<grid, 256, 0, st>>>(wb);
+        else wgrad_mm_kernel<1, 1, 2, 2><<<grid, 256, 0, st>>>(wb);
+        CHECK_LAUNCH("wgrad_mm_kernel");
+        return launch_reduce_batch(dd, n, dw, db, woff, wsk, wsn, bias_taps, st);
+    }
     switch (cfg) {
     case 0: BY_DT(d.dt, (wgrad_f32_kernel<2, 2, 2, 2, true, 32, T><<<grid, 256, 0, st>>>(wb))); break;
     case 1: BY_DT(d.dt, (wgrad_f32_kernel<2, 1, 2, 2, true, 32, T><<<grid, 256, 0, st>>>(wb))); break;
