@@ -263,19 +263,17 @@ bool line_x3_ok(const IgemmDesc &d, LineDesc &ld)
 }
 int run_line_x3(LineDesc ld, int NC, hipStream_t st)
 {
-    // 64 channels: 64-pixel tiles, two independent blocks per CU (each fills the other's barrier,
-    // latency and epilogue gaps); ERFNET_X3_BM128=1: 128-pixel tiles, one block per CU (experiments)
-    static int bm128 = -1;
-    if (bm128 < 0) { const char *e = getenv("ERFNET_X3_BM128"); bm128 = (e && atoi(e)) ? 1 : 0; }
-    const int BM = (NC == 128 || !bm128) ? 64 : 128;
+    // 64 channels: two independent blocks per CU (each fills the other's barrier, latency and
+    // epilogue gaps); 128 channels with lines of at most 32 pixels: 32-pixel tiles
+    const int BM = (NC == 128 && ld.L <= 32) ? 32 : 64;
     ld.segs = (ld.L + BM - 1) / BM;
     const int ntiles = ld.nlines * ld.segs;
     if (ntiles <= 0) return 0;
-    const int slots = cu_count() * (NC == 64 && BM == 64 ? 2 : 1);
+    const int slots = cu_count() * (NC == 64 ? 2 : 1);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-    if (NC == 128) line_x3_kernel<128, 64><<<grid, 256, 0, st>>>(ld);
-    else if (BM == 64) line_x3_kernel<64, 64><<<grid, 256, 0, st>>>(ld);
-    else line_x3_kernel<64, 128><<<grid, 256, 0, st>>>(ld);
+    if (NC == 128 && BM == 32) line_x3_kernel<128, 32><<<grid, 256, 0, st>>>(ld);
+    else if (NC == 128) line_x3_kernel<128, 64><<<grid, 256, 0, st>>>(ld);
+    else line_x3_kernel<64, 64><<<grid, 256, 0, st>>>(ld);
     CHECK_LAUNCH("line_x3_kernel");
     return 0;
 }

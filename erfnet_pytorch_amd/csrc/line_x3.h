@@ -32,7 +32,7 @@ __device__ __forceinline__ unsigned x3_cvt2(f32x2 v)
 }
 
 template <int NC, int BM>
-__global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel(const LineDesc d)
+__global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3_kernel(const LineDesc d)
 {
     constexpr int GC = NC / 32, GP = 4 / GC, WM = BM / (32 * GP);
     static_assert((WM == 1 || WM == 2) && WM * GP * 32 == BM, "tile shape: one or two 32-pixel MFMA tiles per wave");
@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
     constexpr int FPITCH = NC * 4, TF = BM * FPITCH;
     constexpr int RPP = 256 / F4R;              // rows per copy pass of the block
     constexpr int PASSES = BM / RPP;            // float4 per thread and tile
-    static_assert(PASSES % KS == 0 && PASSES / KS <= 2, "conversions per k-step");
-    constexpr int PER = PASSES / KS;
-    static_assert(PER <= WM || PER == WM, "six pieces per conversion over 6 * WM MFMA slots");
+    // one staged float4 per k-step (<128,64>, <64,64>) or per second k-step (<128,32>)
+    static_assert(KS % PASSES == 0 && (WM == 1 || PASSES == KS), "conversion schedule");
+    constexpr int CSTRIDE = KS / PASSES;
     constexpr int OFF_TAP = 0, OFF_RES = 2 * T3, OFF_CST = OFF_RES + TF;
     static_assert(OFF_CST + 2 * NC * 4 <= 160 * 1024, "LDS budget");
     constexpr size_t PL = (size_t)3 * NC * NC;  // elements per weight plane
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
     };
 
     // One tap: 6 x WM MFMAs per k-step (terms lh hl mm mh hm hh per pixel tile), one piece of side
-    // work behind each: the fragment reads of the next k-step, then the split of PER float4 of the
+    // work behind each: the fragment reads of the next k-step, then the split of a float4 of the
     // staged tile into the other TAP buffer and the load of the same float4 of the tile after it.
     auto run_tap = [&](auto tap_c, auto first_c, int seq, const Cur &nx) __attribute__((always_inline)) {
         constexpr int TAP = decltype(tap_c)::value;
@@ -277,9 +277,12 @@ __global__ __launch_bounds__(256, (NC * BM <= 4096 ? 2 : 1)) void line_x3_kernel
                     const int P = j % 3, ot = j < 3 ? OT1 : OT2;
                     w[P][ot][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + P * PL + ((size_t)((ot * KS + s) * GC + cg) * 64 + lane) * 8);
                 }
-                // 6 * PER conversion pieces over the 6 * WM slots: one per slot, or the second half
-                if (PER == WM) piece(PER * s + j / 6, j % 6);
-                else if (j >= 3 * WM) piece(s, j - 3 * WM);
+                // the six pieces of a conversion: one per slot (WM = 1), or the second half of the slots
+                if (WM == 1) {
+                    if (s % CSTRIDE == 0) piece(s / CSTRIDE, j);
+                } else if (j >= 6) {
+                    piece(s, j - 6);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
