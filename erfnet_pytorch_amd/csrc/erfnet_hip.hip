@@ -59,9 +59,24 @@ Switch g_sw_pair("ERFNET_NO_PAIR"), g_sw_wgrad_line("ERFNET_NO_WGRAD_LINE"), g_s
 Switch g_sw_pair16("ERFNET_PAIR16", 0);
 std::atomic<int> g_line2{1};        // ERF_OPT_LINE2
 // fp32 64 / 128-channel 1-D convolutions on the bf16 matrix pipe, operands split in three bf16 terms
-// (line_x3_kernel, wgrad_line_x3_kernel): fp32 accuracy at 2.7x the fp32 matrix rate.  ERFNET_NO_X3=1
-// or ERF_OPT_SPLIT_BF16 = 0 keeps them on the fp32 MFMA kernels (pair_f32_kernel, wgrad_line_kernel)
-Switch g_sw_x3("ERFNET_NO_X3");
+// (line_x3_kernel, wgrad_line_x3_kernel): fp32 accuracy at 2.7x the fp32 matrix rate.
+// Mode 1 (default): where it pays — a convolution launch takes the split kernel when it has at least
+// two line tiles per resident block (below that the kernel's weight prologue outweighs its faster
+// tiles and the fused fp32 pair wins); 2: always; 0 (ERFNET_NO_X3=1, ERF_OPT_SPLIT_BF16 = 0): never,
+// i.e. the fp32 MFMA kernels (pair_f32_kernel, wgrad_line_kernel).
+std::atomic<int> g_x3_mode{-1};
+int x3_mode()
+{
+    int x = g_x3_mode.load(std::memory_order_relaxed);
+    if (x < 0) {
+        const char *e = getenv("ERFNET_NO_X3");
+        x = (e && atoi(e)) ? 0 : 1;
+        const char *f = getenv("ERFNET_X3_ALWAYS");
+        if (x && f && atoi(f)) x = 2;
+        g_x3_mode.store(x, std::memory_order_relaxed);
+    }
+    return x;
+}
 
 int fail(const char *fmt, ...)
 {
@@ -255,21 +270,28 @@ bool line_geometry(const IgemmDesc &d, LineDesc &ld, bool reads_memory = true)
 const int kCfgLine = 101;
 // the same geometry on fp32 tensors (line_x3_kernel): byte offsets must stay below 2^31
 const int kCfgLineX3 = 102;
+int line_x3_tile(int NC, int L) { return (NC == 128 && L <= 32) ? 32 : 64; }
+int line_x3_slots(int NC) { return cu_count() * (NC == 64 ? 2 : 1); }
 bool line_x3_ok(const IgemmDesc &d, LineDesc &ld)
 {
-    if (d.dt || !g_sw_x3.on()) return false;
+    const int mode = x3_mode();
+    if (d.dt || !mode) return false;
     if ((long long)d.N * d.GH * d.GW * d.K >= (1LL << 29)) return false;
-    return line_geometry(d, ld);
+    if (!line_geometry(d, ld)) return false;
+    if (mode >= 2) return true;
+    const int BM = line_x3_tile(d.K, ld.L);
+    const long long ntiles = (long long)ld.nlines * ((ld.L + BM - 1) / BM);
+    return ntiles >= 2LL * line_x3_slots(d.K);
 }
 int run_line_x3(LineDesc ld, int NC, hipStream_t st)
 {
     // 64 channels: two independent blocks per CU (each fills the other's barrier, latency and
     // epilogue gaps); 128 channels with lines of at most 32 pixels: 32-pixel tiles
-    const int BM = (NC == 128 && ld.L <= 32) ? 32 : 64;
+    const int BM = line_x3_tile(NC, ld.L);
     ld.segs = (ld.L + BM - 1) / BM;
     const int ntiles = ld.nlines * ld.segs;
     if (ntiles <= 0) return 0;
-    const int slots = cu_count() * (NC == 64 ? 2 : 1);
+    const int slots = line_x3_slots(NC);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
     if (NC == 128 && BM == 32) line_x3_kernel<128, 32><<<grid, 256, 0, st>>>(ld);
     else if (NC == 128) line_x3_kernel<128, 64><<<grid, 256, 0, st>>>(ld);
@@ -651,7 +673,10 @@ int pair_variant(const IgemmDesc &a, const IgemmDesc &b, bool ignore_switch = fa
         if (la.pstride == lb.pstride) return 0;             // same axis: not a pair
         return line_tile_bf16(NC, la.L, true);
     }
-    if (!ignore_switch && g_sw_x3.on()) return 0;      // each half takes line_x3_kernel (faster than the fp32 pair)
+    if (!ignore_switch) {       // each half takes line_x3_kernel where that is faster than the fp32 pair
+        LineDesc la, lb;
+        if (line_x3_ok(a, la) && line_x3_ok(b, lb)) return 0;
+    }
     const IgemmDesc *dd[2] = {&a, &b};
     for (const IgemmDesc *d : dd) {
         if (d->K != NC || d->Nout != NC || d->in_C != NC || d->out_C != NC || d->in_coff || d->out_coff) return 0;
@@ -868,7 +893,7 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     const int jtiles = 1;
     // fp32 tensors on the bf16 matrix pipe (split operands): one block per CU; at 64 channels the
     // block's two wave groups write a slab each
-    const bool x3 = !dd[0].dt && g_sw_x3.on();
+    const bool x3 = !dd[0].dt && x3_mode() != 0;
     // 64 channels, dilation <= 4 (every 64-channel block of the network): a 72-row X tile, two
     // 256-thread blocks per CU (independent blocks fill each other's staging phases)
     int maxdil = 0;
@@ -1413,7 +1438,11 @@ int erf_set_option(int option, int value)
     if (option == ERF_OPT_STREAM16) return g_sw_stream16.set(value);
     if (option == ERF_OPT_PAIR16) return g_sw_pair16.set(value);
     if (option == ERF_OPT_LINE2) return g_line2.exchange(value ? 1 : 0);
-    if (option == ERF_OPT_SPLIT_BF16) return g_sw_x3.set(value);
+    if (option == ERF_OPT_SPLIT_BF16) {
+        const int prev = x3_mode();
+        g_x3_mode.store(value < 0 ? 0 : (value > 2 ? 2 : value), std::memory_order_relaxed);
+        return prev;
+    }
     return -1;
 }
 const char *erf_last_error(void) { return g_err; }

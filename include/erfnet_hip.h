@@ -69,12 +69,14 @@ unsigned long long erf_launch_count(void);
 /* ERF_OPT_LINE2 (default 1; ERFNET_NO_LINE2=1): bf16 conv pairs on the eight-wave kernel whose wave
  * groups work on consecutive tiles (line2_bf16_kernel); off = the four-wave kernel; same results. */
 #define ERF_OPT_LINE2 5
-/* ERF_OPT_SPLIT_BF16 (default 1; ERFNET_NO_X3=1 turns it off): the fp32 64/128-channel 1-D
- * convolutions and their weight gradients on the bf16 matrix pipe, each fp32 operand split into three
+/* ERF_OPT_SPLIT_BF16 (default 1; ERFNET_NO_X3=1 -> 0, ERFNET_X3_ALWAYS=1 -> 2): the fp32 64/128-channel
+ * 1-D convolutions and their weight gradients on the bf16 matrix pipe, each fp32 operand split into three
  * bf16 terms (exactly) and six of the nine partial products accumulated in fp32 (line_x3_kernel,
  * wgrad_line_x3_kernel): fp32 storage and fp32-level accuracy (the dropped terms are below 2^-24 of a
- * product), 2.7x the fp32 matrix rate.  Off = the fp32-MFMA kernels (pair_f32_kernel,
- * wgrad_line_kernel); the two agree to fp32 rounding.  Non-finite inputs give NaN on the split path. */
+ * product), 2.7x the fp32 matrix rate.  1 = where it pays: a convolution launch with at least two line
+ * tiles per resident block (smaller launches keep the fused fp32 pair); 2 = every eligible convolution;
+ * 0 = the fp32-MFMA kernels (pair_f32_kernel, wgrad_line_kernel).  The paths agree to fp32 rounding.
+ * Non-finite inputs give NaN on the split path. */
 #define ERF_OPT_SPLIT_BF16 6
 int erf_set_option(int option, int value);
 

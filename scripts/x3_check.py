@@ -24,7 +24,7 @@ def ref64(blk, x, gy):
     return y.detach(), x.grad, {n: p.grad for n, p in P.items()}
 
 def run(blk, x, gy, opt):
-    _lib.lib().erf_set_option(_lib.OPT_SPLIT_BF16, opt)
+    _lib.lib().erf_set_option(_lib.OPT_SPLIT_BF16, 2 * opt)
     blk.zero_grad(set_to_none=True)
     xt = x.clone().requires_grad_(True)
     y = blk(xt); y.backward(gy)
@@ -51,7 +51,7 @@ for (c, d, shape) in ((128, 2, (6, 128, 64, 128)), (64, 1, (6, 64, 128, 256)), (
     gy = torch.randn(shape, device="cuda").contiguous(memory_format=torch.channels_last)
     y64, dx64, g64 = ref64(blk, x, gy)
     res = [run(blk, x, gy, 0), run(blk, x, gy, 1)]
-    _lib.lib().erf_set_option(_lib.OPT_SPLIT_BF16, 0)
+    _lib.lib().erf_set_option(_lib.OPT_SPLIT_BF16, 1)
     print(f"C={c} d={d} {shape}: fwd+bwd ms fp32 {res[0][3]:.4f} split {res[1][3]:.4f}")
     for nm, (y, dx, g, _) in zip(("fp32 ", "split"), res):
         ey = (y.double().cpu() - y64).abs()

@@ -17,7 +17,7 @@ DEV = "cuda:0"
 @pytest.fixture
 def split_on():
     from erfnet_pytorch_amd import _lib
-    prev = _lib.set_option(_lib.OPT_SPLIT_BF16, 1)
+    prev = _lib.set_option(_lib.OPT_SPLIT_BF16, 2)      # 2 = every eligible convolution, whatever its size
     yield
     _lib.set_option(_lib.OPT_SPLIT_BF16, prev)
 
@@ -80,7 +80,7 @@ def test_split_path_is_as_accurate_as_fp32_mfma():
         o = F.conv2d(o, m.weight.double().cpu(), m.bias.double().cpu(), padding=m.padding, dilation=m.dilation)
         o = F.relu(o + xd) if i == 3 else F.relu(o)
     ys = []
-    for opt in (0, 1):
+    for opt in (0, 2):
         prev = _lib.set_option(_lib.OPT_SPLIT_BF16, opt)
         try:
             with torch.no_grad():
