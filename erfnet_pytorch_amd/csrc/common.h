@@ -86,6 +86,8 @@ struct IgemmDesc {
     int Npad;          // padded column count of wp (multiple of the block's BN)
     int cfg;           // host side: tile configuration chosen by plan_igemm
     int vec_ok;        // in_C, in_coff, K all multiples of 4 and `in` 16-byte aligned
+    double *bn_partial;    // host side, may be null: line_x3_kernel leaves per-block column sums of the output
+                           // and of its squares here ([blocks][2 * Nout]: train-mode BatchNorm statistics)
 };
 
 // Weight gradient: dW[t][k][j] = sum_m in[src(m,t)][k] * g[gpix(m,t)][j], reduced over pixels in

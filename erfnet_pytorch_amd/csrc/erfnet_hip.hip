@@ -283,6 +283,16 @@ bool line_x3_ok(const IgemmDesc &d, LineDesc &ld)
     const long long ntiles = (long long)ld.nlines * ((ld.L + BM - 1) / BM);
     return ntiles >= 2LL * line_x3_slots(d.K);
 }
+// blocks line_x3_kernel is launched with for this convolution (rows of IgemmDesc::bn_partial)
+int line_x3_grid(const IgemmDesc &d)
+{
+    LineDesc ld;
+    if (!line_geometry(d, ld)) return 0;
+    const int BM = line_x3_tile(d.K, ld.L);
+    const long long ntiles = (long long)ld.nlines * ((ld.L + BM - 1) / BM);
+    const int slots = line_x3_slots(d.K);
+    return (int)(ntiles < slots ? ntiles : slots);
+}
 int run_line_x3(LineDesc ld, int NC, hipStream_t st)
 {
     // 64 channels: two independent blocks per CU (each fills the other's barrier, latency and
@@ -293,9 +303,16 @@ int run_line_x3(LineDesc ld, int NC, hipStream_t st)
     if (ntiles <= 0) return 0;
     const int slots = line_x3_slots(NC);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-    if (NC == 128 && BM == 32) line_x3_kernel<128, 32><<<grid, 256, 0, st>>>(ld);
-    else if (NC == 128) line_x3_kernel<128, 64><<<grid, 256, 0, st>>>(ld);
-    else line_x3_kernel<64, 64><<<grid, 256, 0, st>>>(ld);
+#define X3_LAUNCH(nc, bm)                                                                           \
+    do {                                                                                            \
+        if (ld.stats) line_x3_kernel<nc, bm, true><<<grid, 256, 0, st>>>(ld);                       \
+        else line_x3_kernel<nc, bm, false><<<grid, 256, 0, st>>>(ld);                               \
+    } while (0)
+    if (NC == 128 && BM == 32) X3_LAUNCH(128, 32);
+    else if (NC == 128) X3_LAUNCH(128, 64);
+    else if (ld.stats) return fail("line_x3_kernel: output statistics are built for 128 channels only");
+    else line_x3_kernel<64, 64, false><<<grid, 256, 0, st>>>(ld);
+#undef X3_LAUNCH
     CHECK_LAUNCH("line_x3_kernel");
     return 0;
 }
@@ -529,6 +546,7 @@ int run_igemm_t(const IgemmDesc &d, hipStream_t st)
         LineDesc ld;
         if (!line_geometry(d, ld)) return fail("igemm: line plan without line geometry");
         ld.wp1 = (const bf16_t *)d.wp;
+        ld.stats = d.bn_partial;
         return run_line_x3(ld, d.K, st);
     }
     if (d.cfg == kCfgStream16) {
@@ -1250,10 +1268,19 @@ int bn_stats_launch(int dt, const BnStatsDesc &s, bool bwd, Arena &ar, hipStream
 }
 
 // Batch statistics of pre [M][C] -> bn->save_mean / save_invstd (+ running stats).
-int bn_train_stats(int dt, const erf_bn_t *bn, const void *pre, long long M, int C, Arena &ar, hipStream_t st)
+// `conv_partial` (conv_rows > 0): the producing convolution already left that many per-block partial rows.
+int bn_train_stats(int dt, const erf_bn_t *bn, const void *pre, long long M, int C, Arena &ar, hipStream_t st,
+                   const double *conv_partial = nullptr, int conv_rows = 0)
 {
     if (C > 256) return fail("BatchNorm kernels support C <= 256 (C = %d)", C);
     if (!bn->save_mean || !bn->save_invstd) return fail("BatchNorm train mode needs save_mean/save_invstd");
+    if (conv_partial && conv_rows > 0) {
+        bn_reduce_finalize_kernel<<<(C + 7) / 8, 256, 0, st>>>(conv_partial, conv_rows, bn->save_mean, bn->save_invstd,
+                                                              bn->running_mean, bn->running_var,
+                                                              bn->num_batches_tracked, M, C, bn->momentum, bn->eps);
+        CHECK_LAUNCH("bn_reduce_finalize_kernel");
+        return 0;
+    }
     if (C % 4 == 0 && aligned16(pre)) {
         // per-block partial rows, then one launch that adds them in a fixed order and finalises
         const int G = bn_stats_blocks(M, C);
@@ -1614,6 +1641,22 @@ static int downsampler_backward_impl(int dt, const void *x, long long sn, long l
 // Launch plan per block: conv3x1_1 | conv1x3_1 + conv3x1_2 (pair over image columns) | conv1x3_2;
 // inside a chain a block's conv1x3_2 and the next block's conv3x1_1 form one more such pair
 // ("along W, then along H"), whose intermediate is the block output.
+// If `d` (planned) runs on line_x3_kernel and has no mask / residual / ReLU epilogue, reserve its
+// statistics rows and return their number; else 0 (ERFNET_NO_BN_FUSE=1: never — experiments).
+int conv_stats_rows(IgemmDesc &d, Arena &ar)
+{
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("ERFNET_NO_BN_FUSE"); off = (e && atoi(e)) ? 1 : 0; }
+    d.bn_partial = nullptr;
+    // (128 channels only: at 64 channels, two blocks per CU, the extra state spills and the fused kernel
+    // costs more than the statistics pass it saves — measured 94 us against 45 + 9)
+    if (off || d.cfg != kCfgLineX3 || d.K != 128 || d.epi.mask || d.epi.res || d.epi.relu || d.epi.bn.on) return 0;
+    const int rows = line_x3_grid(d);
+    if (rows <= 0) return 0;
+    d.bn_partial = (double *)ar.take(sizeof(double) * 2 * (size_t)d.Nout * rows);
+    return d.bn_partial ? rows : 0;
+}
+
 namespace {
 struct Nb1dPlan {
     IgemmDesc d[4];
@@ -1716,9 +1759,12 @@ int nb1d_chain_segment(int dt, const void *x, const erf_nb1d_block_t *blk, int n
         if (P.pair12) {
             if (run_pair(P.pd12, C, P.pair12, st)) return 1;
         } else {
+            // train-mode BatchNorm behind a convolution on line_x3_kernel: the kernel leaves the column
+            // sums of its output, the separate statistics pass is skipped
+            const int g1 = P.m1 == 2 ? conv_stats_rows(P.d[1], ar) : 0;
             if (run_igemm(P.d[1], st)) return 1;
             if (P.tp1) {
-                if (P.m1 == 2) { if (bn_train_stats(dt, B.bn1, P.p2, M, C, ar, st)) return 1; }
+                if (P.m1 == 2) { if (bn_train_stats(dt, B.bn1, P.p2, M, C, ar, st, P.d[1].bn_partial, g1)) return 1; }
                 else if (bn_eval_prepare(B.bn1, C, st)) return 1;
                 Epilogue e = kNoEpi;
                 e.bn = P.m1 == 2 ? bn_saved_affine(B.bn1) : bn_eval_affine(B.bn1);
@@ -1731,9 +1777,10 @@ int nb1d_chain_segment(int dt, const void *x, const erf_nb1d_block_t *blk, int n
             if (run_pair(P.pdn, C, P.pair_next, st)) return 1;
             continue;
         }
+        const int g2 = (P.tp2 && P.m2 == 2) ? conv_stats_rows(P.d[3], ar) : 0;
         if (run_igemm(P.d[3], st)) return 1;
         if (P.tp2) {
-            if (P.m2 == 2) { if (bn_train_stats(dt, B.bn2, P.p4, M, C, ar, st)) return 1; }
+            if (P.m2 == 2) { if (bn_train_stats(dt, B.bn2, P.p4, M, C, ar, st, P.d[3].bn_partial, g2)) return 1; }
             else if (bn_eval_prepare(B.bn2, C, st)) return 1;
             Epilogue e = kNoEpi;
             e.bn = P.m2 == 2 ? bn_saved_affine(B.bn2) : bn_eval_affine(B.bn2);

@@ -38,6 +38,8 @@ struct LineDesc {
     int pstride;                // pixel-index distance between neighbours on a line
     int qstride;                // pixel-index distance between the bases of neighbouring lines
     int s1[3], s2[3];
+    double *stats;              // line_x3_kernel only, may be null: [blocks][2 * NC] per-block column sums of the
+                                // output and of its squares (train-mode BatchNorm statistics)
 #ifdef ERF_LINE_STAMPS
     unsigned long long *stamps;     // diagnostic build only: [block][32] shader-clock stamps of wave 0
 #endif

@@ -31,7 +31,8 @@ __device__ __forceinline__ unsigned x3_cvt2(f32x2 v)
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32 (RNE)
 }
 
-template <int NC, int BM>
+// STATS: the variant that also leaves the column sums of its output (LineDesc::stats).
+template <int NC, int BM, bool STATS = false>
 __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3_kernel(const LineDesc d)
 {
     constexpr int GC = NC / 32, GP = 4 / GC, WM = BM / (32 * GP);
@@ -47,10 +48,15 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3_kernel(const 
     static_assert(KS % PASSES == 0 && (WM == 1 || PASSES == KS), "conversion schedule");
     constexpr int CSTRIDE = KS / PASSES;
     constexpr int OFF_TAP = 0, OFF_RES = 2 * T3, OFF_CST = OFF_RES + TF;
-    static_assert(OFF_CST + 2 * NC * 4 <= 160 * 1024, "LDS budget");
+    // optional output statistics: per-thread partial sums of a tile (8 floats), running sums (doubles)
+    constexpr int OFF_SPT = OFF_CST + 2 * NC * 4, OFF_RUN = OFF_SPT + (STATS ? 256 * 32 : 0);
+    constexpr int LDS_BYTES = OFF_RUN + (STATS ? 2 * NC * 8 : 0);
+    static_assert(LDS_BYTES * (NC == 64 ? 2 : 1) <= 160 * 1024, "LDS budget");
     constexpr size_t PL = (size_t)3 * NC * NC;  // elements per weight plane
-    __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_CST + 2 * NC * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     float *cst = reinterpret_cast<float *>(lds + OFF_CST);          // sc[NC] sh[NC]
+    double *run = reinterpret_cast<double *>(lds + OFF_RUN);        // sum[NC] sumsq[NC]
+    constexpr bool want_stats = STATS;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3_kernel(const 
         float sc, sh;
         epi_channel_affine(d.epi1, c, sc, sh);
         cst[c] = sc; cst[NC + c] = sh;
+        if (STATS) { run[c] = 0.0; run[NC + c] = 0.0; }
     }
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
@@ -370,6 +377,37 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3_kernel(const 
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), rout, (int)vo[i], (int)soff, 0);
         }
     };
+    // Optional statistics of the output (train-mode BatchNorm: the tile holds conv + bias, no mask or
+    // residual follows): a thread sums ITS channel quad over the tile's rows (it reads the chunk where
+    // the swizzle put that quad), leaves the partial sums in LDS, and after the tile's last barrier
+    // the first F4R threads add the RPP partial rows to the block's running sums in double — a fixed
+    // order, so the statistics are bitwise reproducible.
+    float *spt = reinterpret_cast<float *>(lds + OFF_SPT);
+    auto stats_tile = [&](const Geo &g) __attribute__((always_inline)) {
+        f32x4 s1 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, s2 = s1;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int r = p * RPP + r0;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(lds + OFF_RES + (r * F4R + (c4 ^ (r & (F4R - 1)))) * 16);
+            if (r < g.len) { s1 = s1 + v; s2 = s2 + v * v; }
+        }
+        *reinterpret_cast<f32x4 *>(spt + tid * 8) = s1;
+        *reinterpret_cast<f32x4 *>(spt + tid * 8 + 4) = s2;
+    };
+    auto stats_fold = [&]() __attribute__((always_inline)) {
+        if (tid < F4R) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double a = 0.0, b = 0.0;
+                for (int q = 0; q < RPP; ++q) {
+                    a += (double)spt[(q * F4R + tid) * 8 + e];
+                    b += (double)spt[(q * F4R + tid) * 8 + 4 + e];
+                }
+                run[4 * tid + e] += a;
+                run[NC + 4 * tid + e] += b;
+            }
+        }
+    };
 
     clear_acc();
     int seq = 0;
@@ -404,10 +442,19 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3_kernel(const 
         lds_barrier();
         X3_STAMP();
         sweep_tile(g);
+        if (want_stats) stats_tile(g);          // (block-uniform)
         X3_STAMP();         // output pass issued
         lds_barrier();          // the fp32 tile may be refilled; the stores stay in flight
+        if (want_stats) stats_fold();           // (the partial rows are rewritten three barriers from here)
         X3_STAMP();
     };
     tile_body(std::true_type{}, 0);
     for (int k = 1; k < K; ++k) tile_body(std::false_type{}, k);
+    if (want_stats && tid < F4R) {              // the threads that kept the running sums
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d.stats[(size_t)blockIdx.x * 2 * NC + 4 * tid + e] = run[4 * tid + e];
+            d.stats[(size_t)blockIdx.x * 2 * NC + NC + 4 * tid + e] = run[NC + 4 * tid + e];
+        }
+    }
 }
