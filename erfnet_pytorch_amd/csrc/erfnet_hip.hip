@@ -955,7 +955,13 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     const int max_split = nsplit;
     dim3 grid((unsigned)max_split, jtiles, n);
     if (x3) {
-        if (NC == 128) wgrad_line_x3_kernel<128, 1, 2, 4, 2, 1, 1><<<grid, 512, 0, st>>>(wb);
+        // 128 channels: four waves with 64 x 64 outputs each (192 accumulator registers, one wave per
+        // SIMD) — the eight-wave 32 x 64 tiling reads 15 fragments per 36 MFMAs and is bound by LDS reads
+        // (measured 122 us against 111); ERFNET_X3_WGRAD_8W=1 selects it (experiments)
+        static int w8 = -1;
+        if (w8 < 0) { const char *e = getenv("ERFNET_X3_WGRAD_8W"); w8 = (e && atoi(e)) ? 1 : 0; }
+        if (NC == 128 && !w8) wgrad_line_x3_kernel<128, 2, 2, 2, 2, 1, 1><<<grid, 256, 0, st>>>(wb);
+        else if (NC == 128) wgrad_line_x3_kernel<128, 1, 2, 4, 2, 1, 1><<<grid, 512, 0, st>>>(wb);
         else if (x3_small) wgrad_line_x3_kernel<64, 1, 1, 2, 2, 1, 2, 72><<<grid, 256, 0, st>>>(wb);
         else wgrad_line_x3_kernel<64, 1, 1, 2, 2, 2, 1><<<grid, 512, 0, st>>>(wb);
     } else if (dd[0].dt) {         // bf16 tensors: bf16 MFMA, fragments through the transposing LDS read
