@@ -148,6 +148,43 @@ def dominant_kernel_roofline(device, batch):
     return out
 
 
+def dominant_kernel_roofline_bf16(device, batch):
+    """--dtype bf16: line2_bf16_kernel<128,64> — two chained 1-D convolutions 128 -> 128 channels over
+    batch x 64 x 128 pixels in one launch (conv1x3 then conv3x1, intermediate stored as in a training
+    forward), bf16 operands, fp32 accumulation: the kernel the bf16 step spends most of its time in.
+    erf_conv_pair_forward_bf16 issues exactly one launch per call (weights packed once)."""
+    import ctypes as C
+    from erfnet_pytorch_amd import _lib
+    lib = _lib.lib()
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(batch, DOM_C, DOM_H, DOM_W, generator=g).clamp_(min=0).to(device).to(torch.bfloat16)
+    x = x.contiguous(memory_format=torch.channels_last)
+    wa = (torch.randn(DOM_C, DOM_C, 3, generator=g) * 0.05).to(device)
+    wb = (torch.randn(DOM_C, DOM_C, 3, generator=g) * 0.05).to(device)
+    b = torch.zeros(DOM_C, device=device)
+    packed = torch.empty(2 * 3 * DOM_C * DOM_C, dtype=torch.bfloat16, device=device)
+    st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    _lib.check(lib.erf_conv_pair_pack_bf16(ptr(wa), ptr(wb), DOM_C, ptr(packed), st))
+    y, mid = torch.empty_like(x), torch.empty_like(x)
+
+    def call():
+        _lib.check(lib.erf_conv_pair_forward_bf16(ptr(x), ptr(packed), ptr(b), ptr(b), 1, 2, 2, 1, 1, None, ptr(mid),
+                                                  ptr(y), batch, DOM_C, DOM_H, DOM_W, st))
+    ms = event_time_ms(call, device, 50)
+    pixels = batch * DOM_H * DOM_W
+    flops = 2 * 2.0 * pixels * (3 * DOM_C) * DOM_C
+    nbytes = 3 * pixels * DOM_C * 2
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": BF16_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / BF16_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "line2_bf16_kernel<128,64> (conv1x3 + conv3x1, 128->128 channels, one launch, bf16 tensors)",
+            "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": nbytes,
+            "hbm_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+
 def harness_loop(call, device, batch, iters):
     """The loop of eval/eval_forwardTime.py:40-55: device synchronised around every call, the first
     call excluded, time per image = t / B (the script's sleep(1) dropped)."""
@@ -439,7 +476,8 @@ def main():
         if world == 1:
             del model, opt, params, reducer
             torch.cuda.empty_cache()
-            rec["roofline"] = dominant_kernel_roofline(device, args.batch)
+            rec["roofline"] = (dominant_kernel_roofline_bf16(device, args.batch) if args.dtype == "bf16" else
+                               dominant_kernel_roofline(device, args.batch))
             if not args.no_extras:
                 other = "bf16" if args.dtype == "f32" else "f32"
                 rec["train_other_dtype"] = train_rate(device, args.model, other, args.batch, 10, 3)
