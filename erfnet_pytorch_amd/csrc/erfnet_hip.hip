@@ -1007,7 +1007,15 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
         for (int i = 0; i < n; ++i)
             b16 = b16 && dd[i].in_C % 8 == 0 && dd[i].in_coff % 8 == 0 && dd[i].g_C % 8 == 0 && dd[i].g_coff % 8 == 0 &&
                   aligned16(dd[i].in) && aligned16(dd[i].g);
-        const int gran = NW * (b16 ? 32 : 16);
+        // fp32 tensors: the same kernel with split operands (ERF_OPT_SPLIT_BF16); ERFNET_NO_WGRAD16_X3=1 keeps
+        // them on the fp32 MFMA (experiments)
+        static int no16x3 = -1;
+        if (no16x3 < 0) { const char *e = getenv("ERFNET_NO_WGRAD16_X3"); no16x3 = (e && atoi(e)) ? 1 : 0; }
+        bool x16 = d.dt == 0 && x3_mode() != 0 && !no16x3;
+        for (int i = 0; i < n; ++i)
+            x16 = x16 && dd[i].in_C % 4 == 0 && dd[i].in_coff % 4 == 0 && dd[i].g_C % 4 == 0 && dd[i].g_coff % 4 == 0 &&
+                  aligned16(dd[i].in) && aligned16(dd[i].g);
+        const int gran = NW * ((b16 || x16) ? 32 : 16);
         long long sp = (M + nsplit - 1) / nsplit;
         sp = (sp + gran - 1) / gran * gran;
         nsplit = (M + sp - 1) / sp;
@@ -1018,6 +1026,7 @@ int launch_wgrad_batch(WgradDesc *dd, int n, float *const *dw, float *const *db,
             e.partial = ar.floats(slab * nsplit);
             if (!e.partial) return fail("wgrad: workspace too small (%zu floats needed)", slab * nsplit);
             if (b16) wgrad16_bf16_kernel<NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e);
+            else if (x16) wgrad16_x3_kernel<NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e);
             else BY_DT(d.dt, (wgrad16_kernel<T, 3, NW><<<(unsigned)nsplit, NW * 64, 0, st>>>(e)));
             CHECK_LAUNCH("wgrad16_kernel");
         }

@@ -658,3 +658,117 @@ __global__ __launch_bounds__(NW * 64) void wgrad16_bf16_kernel(const WgradDesc d
             for (int t = 0; t < NTAPS; ++t) P[NTAPS * 256 + t * 16 + (e - NTAPS * 256)] = s;
     }
 }
+
+
+// wgrad16_bf16_kernel for fp32 tensors with split operands (x = xh + xm + xl in bf16, six of the nine
+// partial products, fp32 accumulation: fp32 accuracy, see line_x3.h): a lane loads 8 channels of its
+// staging pixel as two float4 per tensor, splits them and writes three bf16 planes per staged tile
+// (12 KiB of LDS per wave); 18 MFMAs per 32 pixels.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad16_x3_kernel(const WgradDesc d)
+{
+    constexpr int NTAPS = 3, SLOTS = NTAPS * 256 + 16;
+    __shared__ float red[NW][SLOTS];
+    __shared__ __attribute__((aligned(16))) unsigned char stage[NW][4][3][32 * 32];     // G, X(tap 0..2) x planes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int pl = lane >> 1, half = lane & 1;              // staging role: pixel of the chunk, channel half
+    const unsigned M = (unsigned)d.N * d.GH * d.GW;
+    const unsigned H = (unsigned)d.GH, W = (unsigned)d.GW;
+    const unsigned wsp = (unsigned)d.split_pixels / NW;              // multiple of 32 (host)
+    const unsigned wbeg = blockIdx.x * (unsigned)d.split_pixels + wave * wsp;
+    unsigned wend = wbeg + wsp;
+    if (wend > M) wend = M;
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(d.in, M * d.in_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_g = make_rsrc(d.g, M * d.g_C * 4u);
+
+    f32x4 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float bsum = 0.0f;
+
+    unsigned q0 = (wbeg < M ? wbeg : 0u) + pl;
+    unsigned oh = (q0 / W) % H, ow = q0 % W;
+    f32x4 rg[2], rx[NTAPS][2];
+    auto load_chunk = [&](unsigned m0) __attribute__((always_inline)) {
+        const unsigned m = m0 + pl;
+        const bool valid = m < wend;
+        const unsigned og = valid ? (m * d.g_C + d.g_coff + 8 * half) * 4u : ERF_OOB;
+        rg[0] = buf_load4(r_g, og);
+        rg[1] = buf_load4(r_g, og + 16u);
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            const int ih = (int)oh + d.tdh[t], iw = (int)ow + d.tdw[t];
+            const bool ok = valid && (unsigned)ih < H && (unsigned)iw < W;
+            const unsigned off = ok ? ((unsigned)((int)m + d.tdh[t] * (int)W + d.tdw[t]) * d.in_C + d.in_coff + 8 * half) * 4u : ERF_OOB;
+            rx[t][0] = buf_load4(r_x, off);
+            rx[t][1] = buf_load4(r_x, off + 16u);
+        }
+        ow += 32;
+        while (ow >= W) { ow -= W; oh = oh + 1 == H ? 0u : oh + 1; }
+    };
+    // 8 values -> 16 bytes in each of the three planes of a staged tile
+    auto put = [&](unsigned char *tile, const f32x4 (&v)[2]) __attribute__((always_inline)) {
+        u32x4 hi, mid, lo;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const u32x2 h2 = pack_bf16x4(v[k]);
+            const f32x4 r1 = v[k] - unpack_bf16x4(h2);
+            const u32x2 m2 = pack_bf16x4(r1);
+            const u32x2 l2 = pack_bf16x4(r1 - unpack_bf16x4(m2));
+            hi[2 * k] = h2[0]; hi[2 * k + 1] = h2[1];
+            mid[2 * k] = m2[0]; mid[2 * k + 1] = m2[1];
+            lo[2 * k] = l2[0]; lo[2 * k + 1] = l2[1];
+        }
+        unsigned char *dst = tile + pl * 32 + half * 16;
+        *reinterpret_cast<u32x4 *>(dst) = hi;
+        *reinterpret_cast<u32x4 *>(dst + 1024) = mid;
+        *reinterpret_cast<u32x4 *>(dst + 2048) = lo;
+    };
+    unsigned char *st = &stage[wave][0][0][0];
+    if (wbeg < wend) load_chunk(wbeg);
+    for (unsigned m0 = wbeg; m0 < wend; m0 += 32) {
+        put(st, rg);
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) put(st + (1 + t) * 3072, rx[t]);
+        if (m0 + 32 < wend) load_chunk(m0 + 32);
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 gf[3], xf[NTAPS][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            gf[p] = tr_frag16(st + p * 1024, lane);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) xf[t][p] = tr_frag16(st + (1 + t) * 3072 + p * 1024, lane);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum += ((float)gf[2][e] + (float)gf[1][e]) + (float)gf[0][e];
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+            // (X plane, G plane), small terms first: lh hl mm mh hm hh
+            const int px = term == 0 ? 2 : (term == 1 || term == 4 || term == 5 ? 0 : 1);
+            const int pg = term == 1 ? 2 : (term == 0 || term == 3 || term == 5 ? 0 : 1);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t][px], gf[pg], acc[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][t * 256 + (4 * g + r) * 16 + i] = acc[t][r];
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (g == 0) red[wave][NTAPS * 256 + i] = bsum;
+    __syncthreads();
+    float *P = d.partial + (long long)blockIdx.x * (NTAPS * 256 + NTAPS * 16);
+    for (int e = tid; e < SLOTS; e += NW * 64) {
+        float s = red[0][e];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) s += red[w][e];
+        if (e < NTAPS * 256) P[e] = s;
+        else
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) P[NTAPS * 256 + t * 16 + (e - NTAPS * 256)] = s;
+    }
+}
