@@ -34,6 +34,8 @@ def test_nb1d_c_abi_against_oracle_split(split_on, C_, dil, N, H, W):
 @pytest.mark.parametrize("C_,dil,N,H,W,mode,drop", [(64, 2, 2, 20, 24, 2, False), (128, 4, 2, 12, 20, 2, True),
                                                     (64, 8, 1, 20, 24, 1, True)])
 def test_nb1d_c_abi_batchnorm_against_oracle_split(split_on, C_, dil, N, H, W, mode, drop):
+    """BatchNorm variants with the split kernels; at 128 channels in train mode the batch statistics come
+    out of the convolution kernel itself."""
     thp.test_nb1d_c_abi_batchnorm_against_oracle(C_, dil, N, H, W, mode, drop)
 
 
@@ -91,3 +93,27 @@ def test_split_path_is_as_accurate_as_fp32_mfma():
     assert not torch.equal(ys[0], ys[1])
     assert rms[1] <= 1.5 * rms[0] + 1e-9, rms
     assert (ys[1] - o).abs().max().item() <= 2e-6 * o.abs().max().item()
+
+
+def test_batch_statistics_from_the_convolution_kernel(split_on):
+    """Train-mode BatchNorm behind a 128-channel split convolution: the kernel leaves the column sums of
+    its output itself.  Several ragged tiles per block; the running statistics after one forward must
+    equal those of the float64 pre-normalisation tensor (momentum 0.1, unbiased variance)."""
+    from erfnet_pytorch_amd import erfnet_blocks
+    torch.manual_seed(11)
+    blk = erfnet_blocks.non_bottleneck_1d(128, 0.0, 2, use_batchnorm=True).to(DEV).train()
+    x = torch.randn(2, 128, 70, 136, device=DEV).relu_().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        blk(x)
+    xd = x.double().cpu()
+    w = lambda m: (m.weight.detach().double().cpu(), m.bias.detach().double().cpu())
+    o = F.relu(F.conv2d(xd, *w(blk.conv3x1_1), padding=blk.conv3x1_1.padding))
+    pre = F.conv2d(o, *w(blk.conv1x3_1), padding=blk.conv1x3_1.padding)
+    mean = pre.mean(dim=(0, 2, 3))
+    var_unb = pre.var(dim=(0, 2, 3), unbiased=True)
+    got_mean = blk.bn1.running_mean.double().cpu() / 0.1
+    got_var = (blk.bn1.running_var.double().cpu() - 0.9) / 0.1
+    assert (got_mean - mean).abs().max().item() <= 2e-6 * max(1.0, mean.abs().max().item())
+    # (running_var is an fp32 number near 0.9 + 0.1 var: recovering var from it costs ~1e-6 absolute)
+    assert ((got_var - var_unb).abs() - 2e-5 * var_unb).max().item() <= 3e-6
+    assert int(blk.bn1.num_batches_tracked) == 1
