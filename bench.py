@@ -245,10 +245,11 @@ def nb1d_bandwidth(device, height, width, dtype_name):
 
 def train_rate(device, model_name, dtype_name, batch, steps, warmup):
     """images/s of the training step at one GPU (no reducer): extra keys only."""
+    from erfnet_pytorch_amd import optim
     from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
     torch.manual_seed(0)
     model = build_model(model_name).to(device).train()
-    opt = torch.optim.Adam(model.parameters(), 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
+    opt = optim.Adam(model.parameters(), 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
     crit = CrossEntropyLoss2d()
     g = torch.Generator(device="cpu").manual_seed(1000)
     images = torch.rand(batch, 3, HEIGHT, WIDTH, generator=g).to(device).to(act_dtype(dtype_name))
@@ -276,10 +277,10 @@ def imagenet_rate(device, dtype_name, batch=256, steps=5, warmup=2):
     """The ImageNet pre-training step of the encoder (imagenet/erfnet_imagenet.py, imagenet/main.py:
     83-85,168-189): ERFNet(1000) with BatchNorm in train mode and Dropout2d, CrossEntropyLoss,
     SGD(lr 0.1, momentum 0.9, weight decay 1e-4), synthetic 256 x 3 x 224 x 224 batch per GPU."""
-    from erfnet_pytorch_amd import erfnet_imagenet
+    from erfnet_pytorch_amd import erfnet_imagenet, optim
     torch.manual_seed(0)
     model = erfnet_imagenet.ERFNet(1000).to(device).train()
-    opt = torch.optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=1e-4)
+    opt = optim.SGD(model.parameters(), 0.1, momentum=0.9, weight_decay=1e-4)
     crit = torch.nn.CrossEntropyLoss()
     images = torch.randn(batch, 3, 224, 224, device=device).to(act_dtype(dtype_name))
     target = torch.randint(0, 1000, (batch,), device=device)
@@ -373,7 +374,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    from erfnet_pytorch_amd import _lib
+    from erfnet_pytorch_amd import _lib, optim
     from erfnet_pytorch_amd.ddp import GradientReducer
     _lib.lib()                      # fail loudly here if the HIP library is missing
 
@@ -392,14 +393,14 @@ def main():
 
     # Set-up pass (no update): one backward tells the reducer which parameters take part; they are
     # then laid out in flat buffers next to their gradient buckets.  The optimiser keeps the
-    # reference's settings (train/main.py:43-46,213); on the flat buffers torch's fused Adam is the
-    # same element-wise update in one launch per bucket, and parameters that never get a gradient
-    # are skipped as Adam skips them.
+    # reference's settings (train/main.py:43-46,213); on the flat buffers the library's multi-tensor
+    # Adam (erf_adam_step) is the same element-wise update in one launch for the whole model, and
+    # parameters that never get a gradient are skipped as Adam skips them.
     reducer.zero_grad()
     crit(logits_of(model(images)), labels).backward()
     reducer.finish()
     params = reducer.flatten_parameters()
-    opt = torch.optim.Adam(params, 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6, fused=True)
+    opt = optim.Adam(params, 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
 
     def step():
         reducer.zero_grad()

@@ -117,6 +117,10 @@ _PROTOS = {
     "erf_mse_mean_backward": (C.c_int, [vp, vp, vp, vp, ll, vp]),
     "erf_cross_entropy_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int,
                                              C.c_int, ll, vp]),
+    "erf_adam_step": (C.c_int, [C.c_int, vp, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double,
+                                C.c_double, ll, vp]),
+    "erf_sgd_step": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_double, C.c_double, C.c_double, vp]),
+    "erf_ema_update": (C.c_int, [C.c_int, vp, vp, vp, C.c_double, vp]),
 }
 
 # bf16 variants: same argument lists (activation pointers are bf16 tensors, parameters stay fp32)

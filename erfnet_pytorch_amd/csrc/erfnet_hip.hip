@@ -15,8 +15,11 @@
 #include "wgrad_mm.h"
 #include "loss_kernels.h"
 #include "metric_kernels.h"
+#include "optim_kernels.h"
 
 #include <atomic>
+#include <cmath>
+#include <cstdint>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1469,6 +1472,48 @@ int static_scratch(void **out)
 }
 }  // namespace
 
+namespace {
+// Walks the caller's tensor lists in groups of OPT_MAX_TENSORS; one launch per group.
+template <int KIND>
+int opt_launch(const char *what, int count, float *const *p, const float *const *g, float *const *m, float *const *v,
+               const long long *numel, OptDesc d, hipStream_t st)
+{
+    if (count < 0) return fail("%s: negative tensor count", what);
+    if (count && (!p || !g || !numel || (KIND != OPT_EMA && !m) || (KIND == OPT_ADAM && !v)))
+        return fail("%s: null pointer table", what);
+    int i = 0;
+    while (i < count) {
+        d.count = 0;
+        d.aligned = 0;
+        unsigned long long chunks = 0;
+        for (; i < count && d.count < OPT_MAX_TENSORS; ++i) {
+            if (numel[i] < 0) return fail("%s: tensor %d has a negative size", what, i);
+            if (numel[i] == 0) continue;
+            if (!p[i] || !g[i] || (KIND != OPT_EMA && !m[i]) || (KIND == OPT_ADAM && !v[i]))
+                return fail("%s: tensor %d has a null pointer", what, i);
+            const unsigned long long c = ((unsigned long long)numel[i] + OPT_CHUNK - 1) / OPT_CHUNK;
+            if (chunks + c >= (1ull << 31)) {
+                if (d.count == 0) return fail("%s: tensor %d is too large", what, i);
+                break;                                      // goes into the next launch
+            }
+            const int k = d.count++;
+            d.p[k] = p[i]; d.g[k] = g[i];
+            d.m[k] = KIND != OPT_EMA ? m[i] : nullptr;
+            d.v[k] = KIND == OPT_ADAM ? v[i] : nullptr;
+            d.n[k] = numel[i];
+            chunks += c;
+            d.end_chunk[k] = (unsigned)chunks;
+            const uintptr_t bits = (uintptr_t)d.p[k] | (uintptr_t)d.g[k] | (uintptr_t)d.m[k] | (uintptr_t)d.v[k];
+            if ((bits & 15) == 0) d.aligned |= 1u << k;
+        }
+        if (d.count == 0) continue;
+        opt_step_kernel<KIND><<<(unsigned)chunks, OPT_BLOCK, 0, st>>>(d);
+        CHECK_LAUNCH("opt_step_kernel");
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int erf_version(void) { return 100; }
@@ -2555,6 +2600,43 @@ int erf_mse_mean_backward(const float *a, const float *b, const float *gy, float
     mse_bwd_kernel<<<(unsigned)blocks, ML_BLOCK, 0, st>>>(d);
     CHECK_LAUNCH("mse_bwd_kernel");
     return 0;
+}
+
+// ================================================================================ parameter updates
+int erf_adam_step(int count, float *const *params, const float *const *grads, float *const *exp_avg,
+                  float *const *exp_avg_sq, const long long *numel, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, long long step, void *stream)
+{
+    if (step < 1) return fail("adam: step counts from 1 (got %lld)", step);
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0)) return fail("adam: betas outside [0, 1)");
+    if (!(eps >= 0.0) || !(lr >= 0.0) || !(weight_decay >= 0.0)) return fail("adam: negative lr / eps / weight decay");
+    OptDesc d;
+    memset(&d, 0, sizeof(d));
+    // the scalars in double, as torch.optim.Adam forms them on the host, rounded once for the kernel
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    d.c0 = (float)(1.0 - beta1); d.c1 = (float)beta2; d.c2 = (float)(1.0 - beta2);
+    d.c3 = (float)(lr / bc1); d.c4 = (float)sqrt(bc2); d.c5 = (float)eps;
+    d.wd = (float)weight_decay;
+    return opt_launch<OPT_ADAM>("adam", count, params, grads, exp_avg, exp_avg_sq, numel, d, (hipStream_t)stream);
+}
+
+int erf_sgd_step(int count, float *const *params, const float *const *grads, float *const *momentum_buf,
+                 const long long *numel, double lr, double momentum, double weight_decay, void *stream)
+{
+    if (!(lr >= 0.0) || !(momentum >= 0.0) || !(weight_decay >= 0.0)) return fail("sgd: negative lr / momentum / weight decay");
+    OptDesc d;
+    memset(&d, 0, sizeof(d));
+    d.c0 = (float)momentum; d.c3 = (float)lr; d.wd = (float)weight_decay;
+    return opt_launch<OPT_SGD>("sgd", count, params, grads, momentum_buf, nullptr, numel, d, (hipStream_t)stream);
+}
+
+int erf_ema_update(int count, float *const *target, const float *const *source, const long long *numel,
+                   double discount, void *stream)
+{
+    OptDesc d;
+    memset(&d, 0, sizeof(d));
+    d.c0 = (float)(1.0 - discount); d.c1 = (float)discount;
+    return opt_launch<OPT_EMA>("ema", count, target, source, nullptr, nullptr, numel, d, (hipStream_t)stream);
 }
 
 // ================================================================================ iouEval counts

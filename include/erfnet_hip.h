@@ -298,6 +298,27 @@ int erf_iou_add_batch(const long long *pred, const long long *target, long long 
 int erf_accuracy_counts(const float *scores, const long long *target, int N, int K, int H, int W,
                         long long *counts, void *ws, size_t ws_bytes, void *stream);
 
+/* ---- Parameter updates (the optimiser calls and the mean-teacher update of the training loops) as
+ *      multi-tensor launches: `count` tensors per call, the pointer tables and `numel` in HOST memory,
+ *      the tensors themselves fp32 on the device; tensors with numel 0 are skipped; 32 tensors per
+ *      kernel launch (one launch for a model whose parameters live in a few flat buffers).
+ * erf_adam_step replaces torch.optim.Adam(params, lr, betas, eps=eps, weight_decay=wd).step()
+ *   (train/main.py:213, stepped at :381): L2 weight decay added to the gradient, no amsgrad;
+ *   `step` is the 1-based count of this update (bias corrections are formed from it in double on the
+ *   host, as torch does); exp_avg / exp_avg_sq start as zeros and are updated in place.
+ * erf_sgd_step replaces torch.optim.SGD(params, lr, momentum=m, weight_decay=wd).step()
+ *   (imagenet/main.py:83-85): buf = m * buf + (grad + wd * p), p -= lr * buf; a zero buffer on the
+ *   first step gives torch's "buf = grad" initialisation.
+ * erf_ema_update replaces copyWeightsToModelWithDiscount (train/main.py:140-142, called at :390):
+ *   target = target * (1 - discount) + discount * source. */
+int erf_adam_step(int count, float *const *params, const float *const *grads, float *const *exp_avg,
+                  float *const *exp_avg_sq, const long long *numel, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, long long step, void *stream);
+int erf_sgd_step(int count, float *const *params, const float *const *grads, float *const *momentum_buf,
+                 const long long *numel, double lr, double momentum, double weight_decay, void *stream);
+int erf_ema_update(int count, float *const *target, const float *const *source, const long long *numel,
+                   double discount, void *stream);
+
 /* ================================================================================================
  * bf16 storage.  Every block call above exists a second time, suffixed _bf16, for activation tensors
  * stored as bf16 (the reference's half-precision attempt is eval/eval_forwardTime.py:25,
