@@ -3,7 +3,7 @@ import sys
 import torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from erfnet_pytorch_amd import erfnet_nobn, net_classification
+from erfnet_pytorch_amd import erfnet_nobn, net_classification, optim
 from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
 
 DEV = "cuda:0"
@@ -19,7 +19,7 @@ if what == "fwd":
             net(x)
 else:
     net = net_classification.Net(softmax_classes=20).to(DEV).train()
-    opt = torch.optim.Adam([p for p in net.parameters()], 1e-4, eps=1e-4, weight_decay=1e-6)
+    opt = optim.Adam([p for p in net.parameters()], 1e-4, eps=1e-4, weight_decay=1e-6)
     crit = CrossEntropyLoss2d()
     x = torch.rand(6, 3, 512, 1024, device=DEV).to(dtype)
     lab = torch.randint(-1, 20, (6, 512, 1024), device=DEV)
