@@ -365,6 +365,12 @@ def main():
         sys.exit(f"bench.py: WORLD_SIZE {world} (LOCAL_RANK {local_rank}) but only {ndev} GPU(s) are visible; "
                  f"RCCL needs one device per rank")
     if world > 1:
+        # A rank stuck in a collective would otherwise sit silent until the launcher's own limit: dump
+        # every thread's stack and exit instead (ERFNET_BENCH_WATCHDOG_S, default 900 s; 0 disables).
+        import faulthandler
+        limit = float(os.environ.get("ERFNET_BENCH_WATCHDOG_S", "900"))
+        if limit > 0:
+            faulthandler.dump_traceback_later(limit, exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, rank=rank, world_size=world)
