@@ -396,17 +396,17 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const BnStats4Desc dd)
             mean = *reinterpret_cast<const f32x4 *>(d.mean + 4 * cq);
             inv = *reinterpret_cast<const f32x4 *>(d.invstd + 4 * cq);
         }
-        for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
-            const f32x4 xv = Act<T>::ld4(d.x, r * C + 4 * cq);
+        // the rows of a trip are loaded together (several loads in flight per lane) and added in row
+        // order, so the sums equal those of a row-by-row walk bit for bit
+        const bool has_mask = BWD && d.mask != nullptr, has_ns = BWD && d.nscale != nullptr;
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        auto add_row = [&](f32x4 xv, f32x4 g, f32x4 mk, f32x4 ns) __attribute__((always_inline)) {
             if (BWD) {
-                f32x4 g = Act<T>::ld4(d.gy, r * C + 4 * cq);
-                if (d.mask) {
-                    const f32x4 mk = Act<T>::ld4(d.mask, r * C + 4 * cq);
+                if (has_mask) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = mk[e] > 0.0f ? g[e] : 0.0f;
                 }
-                if (d.nscale) {
-                    const f32x4 ns = *reinterpret_cast<const f32x4 *>(d.nscale + (r / d.pix_per_image) * C + 4 * cq);
+                if (has_ns) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] *= ns[e];
                 }
@@ -416,6 +416,29 @@ __global__ __launch_bounds__(256) void bn_stats4_kernel(const BnStats4Desc dd)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s0[e] += xv[e]; s1[e] += xv[e] * xv[e]; }
             }
+        };
+        constexpr int SU = 4;
+        const long long stride = (long long)gridDim.x * RP;
+        long long r = (long long)blockIdx.x * RP + rr;
+        for (; r + (SU - 1) * stride < d.M; r += SU * stride) {
+            f32x4 xv[SU], g[SU], mk[SU], ns[SU];
+#pragma unroll
+            for (int u = 0; u < SU; ++u) xv[u] = Act<T>::ld4(d.x, (r + u * stride) * C + 4 * cq);
+#pragma unroll
+            for (int u = 0; u < SU; ++u) g[u] = BWD ? Act<T>::ld4(d.gy, (r + u * stride) * C + 4 * cq) : zero4;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) mk[u] = has_mask ? Act<T>::ld4(d.mask, (r + u * stride) * C + 4 * cq) : zero4;
+#pragma unroll
+            for (int u = 0; u < SU; ++u)
+                ns[u] = has_ns ? *reinterpret_cast<const f32x4 *>(d.nscale + ((r + u * stride) / d.pix_per_image) * C + 4 * cq) : zero4;
+#pragma unroll
+            for (int u = 0; u < SU; ++u) add_row(xv[u], g[u], mk[u], ns[u]);
+        }
+        for (; r < d.M; r += stride) {
+            const f32x4 g = BWD ? Act<T>::ld4(d.gy, r * C + 4 * cq) : zero4;
+            const f32x4 mk = has_mask ? Act<T>::ld4(d.mask, r * C + 4 * cq) : zero4;
+            const f32x4 ns = has_ns ? *reinterpret_cast<const f32x4 *>(d.nscale + (r / d.pix_per_image) * C + 4 * cq) : zero4;
+            add_row(Act<T>::ld4(d.x, r * C + 4 * cq), g, mk, ns);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -555,6 +578,7 @@ __global__ __launch_bounds__(256) void elt_kernel(const EltDesc d)
 // The same pass for channel counts whose float4 columns divide the block (256 % (C/4) == 0) and
 // 16-byte addressable optional tensors: a thread keeps one channel quad, so the per-channel affine
 // is formed once, rows advance without any division, and every tensor moves as 16-byte accesses.
+#define ROWS_U 4
 template <typename T>
 __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
 {
@@ -566,18 +590,17 @@ __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
     const Epilogue &ep = d.epi;
     const bool has_res = ep.res != nullptr, has_mask = ep.mask != nullptr, has_ns = ep.nscale != nullptr;
     const bool relu = ep.relu != 0;
-    for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
-        const f32x4 v = Act<T>::ld4(d.in, r * C + c);
+    // ROWS_U rows per trip with every load issued before the first use: a wave keeps ROWS_U 16-byte
+    // loads per tensor in flight (a single one left the memory system under-subscribed: 2.9 TB/s)
+    auto finish = [&](long long r, f32x4 v, f32x4 ns, f32x4 rs, f32x4 mk) __attribute__((always_inline)) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = v[e] * sc[e] + sh[e];
         if (has_ns) {
-            const f32x4 ns = *reinterpret_cast<const f32x4 *>(ep.nscale + (r / d.pix_per_image) * C + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] *= ns[e];
         }
         if (has_res) {
-            const f32x4 rs = Act<T>::ld4(ep.res, r * ep.res_C + ep.res_coff + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += rs[e];
         }
@@ -586,11 +609,36 @@ __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
             for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.0f);
         }
         if (has_mask) {
-            const f32x4 mk = Act<T>::ld4(ep.mask, r * ep.mask_C + ep.mask_coff + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = mk[e] > 0.0f ? o[e] : 0.0f;
         }
         Act<T>::st4(d.out, r * C + c, o);
+    };
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const long long stride = (long long)gridDim.x * RP;
+    long long r = (long long)blockIdx.x * RP + rr;
+    for (; r + (ROWS_U - 1) * stride < d.M; r += ROWS_U * stride) {
+        f32x4 v[ROWS_U], ns[ROWS_U], rs[ROWS_U], mk[ROWS_U];
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) v[u] = Act<T>::ld4(d.in, (r + u * stride) * C + c);
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u)
+            rs[u] = has_res ? Act<T>::ld4(ep.res, (r + u * stride) * ep.res_C + ep.res_coff + c) : zero4;
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u)
+            mk[u] = has_mask ? Act<T>::ld4(ep.mask, (r + u * stride) * ep.mask_C + ep.mask_coff + c) : zero4;
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u)
+            ns[u] = has_ns ? *reinterpret_cast<const f32x4 *>(ep.nscale + ((r + u * stride) / d.pix_per_image) * C + c) : zero4;
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) finish(r + u * stride, v[u], ns[u], rs[u], mk[u]);
+    }
+    for (; r < d.M; r += stride) {
+        const f32x4 v = Act<T>::ld4(d.in, r * C + c);
+        const f32x4 rs = has_res ? Act<T>::ld4(ep.res, r * ep.res_C + ep.res_coff + c) : zero4;
+        const f32x4 mk = has_mask ? Act<T>::ld4(ep.mask, r * ep.mask_C + ep.mask_coff + c) : zero4;
+        const f32x4 ns = has_ns ? *reinterpret_cast<const f32x4 *>(ep.nscale + (r / d.pix_per_image) * C + c) : zero4;
+        finish(r, v, ns, rs, mk);
     }
 }
 
@@ -668,16 +716,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const BnBwdDesc 
         mgx[e] = (float)(d.sums[C + ch] * invM);
     }
     const bool has_mask = d.mask != nullptr, has_ns = d.nscale != nullptr, training = d.training != 0;
-    for (long long r = (long long)blockIdx.x * RP + rr; r < d.M; r += (long long)gridDim.x * RP) {
-        const f32x4 xv = Act<T>::ld4(d.x, r * C + c);
-        f32x4 g = Act<T>::ld4(d.gy, r * C + c);
+    auto finish = [&](long long r, f32x4 xv, f32x4 g, f32x4 mk, f32x4 ns) __attribute__((always_inline)) {
         if (has_mask) {
-            const f32x4 mk = Act<T>::ld4(d.mask, r * C + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = mk[e] > 0.0f ? g[e] : 0.0f;
         }
         if (has_ns) {
-            const f32x4 ns = *reinterpret_cast<const f32x4 *>(d.nscale + (r / d.pix_per_image) * C + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] *= ns[e];
         }
@@ -692,6 +736,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const BnBwdDesc 
             }
         }
         Act<T>::st4(d.dx, r * C + c, o);
+    };
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const long long stride = (long long)gridDim.x * RP;
+    long long r = (long long)blockIdx.x * RP + rr;
+    for (; r + (ROWS_U - 1) * stride < d.M; r += ROWS_U * stride) {       // all loads of ROWS_U rows first
+        f32x4 xv[ROWS_U], g[ROWS_U], mk[ROWS_U], ns[ROWS_U];
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) xv[u] = Act<T>::ld4(d.x, (r + u * stride) * C + c);
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) g[u] = Act<T>::ld4(d.gy, (r + u * stride) * C + c);
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) mk[u] = has_mask ? Act<T>::ld4(d.mask, (r + u * stride) * C + c) : zero4;
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u)
+            ns[u] = has_ns ? *reinterpret_cast<const f32x4 *>(d.nscale + ((r + u * stride) / d.pix_per_image) * C + c) : zero4;
+#pragma unroll
+        for (int u = 0; u < ROWS_U; ++u) finish(r + u * stride, xv[u], g[u], mk[u], ns[u]);
+    }
+    for (; r < d.M; r += stride) {
+        const f32x4 mk = has_mask ? Act<T>::ld4(d.mask, r * C + c) : zero4;
+        const f32x4 ns = has_ns ? *reinterpret_cast<const f32x4 *>(d.nscale + (r / d.pix_per_image) * C + c) : zero4;
+        finish(r, Act<T>::ld4(d.x, r * C + c), Act<T>::ld4(d.gy, r * C + c), mk, ns);
     }
 }
 

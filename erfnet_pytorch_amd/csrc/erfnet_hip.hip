@@ -1216,6 +1216,15 @@ unsigned grid_for(long long work_items, int per_block = 256, unsigned cap = 8192
     return (unsigned)g;
 }
 
+// Blocks of the row-structured element-wise kernels (elt_rows_kernel, bn_bwd_apply_rows_kernel) for
+// `steps` block steps of rows: large tensors get 1536 blocks (six per CU) so that every thread makes
+// whole trips of ROWS_U rows; small ones one block per step.
+unsigned rows_grid(long long steps)
+{
+    if (steps >= 1536LL * ROWS_U) return 1536u;
+    return (unsigned)(steps < 1 ? 1 : (steps < 2048 ? steps : 2048));
+}
+
 int launch_elt(int dt, const void *in, void *out, const Epilogue &epi, long long M, int C, int pix_per_image,
                hipStream_t st)
 {
@@ -1228,7 +1237,7 @@ int launch_elt(int dt, const void *in, void *out, const Epilogue &epi, long long
                       (!epi.nscale || aligned16(epi.nscale));
     if (rows) {
         const long long steps = (M * C4 + 255) / 256;
-        BY_DT(dt, (elt_rows_kernel<T><<<(unsigned)(steps < 2048 ? (steps < 1 ? 1 : steps) : 2048), 256, 0, st>>>(e)));
+        BY_DT(dt, (elt_rows_kernel<T><<<rows_grid(steps), 256, 0, st>>>(e)));
     } else {
         BY_DT(dt, (elt_kernel<T><<<grid_for(M * (C / 4)), 256, 0, st>>>(e)));
     }
@@ -1345,7 +1354,7 @@ int bn_backward(int dt, const erf_bn_t *bn, const void *pre, const void *gy, con
     if (256 % C4 == 0 && aligned16(pre) && aligned16(gy) && aligned16(dx) && (!mask || aligned16(mask)) &&
         (!nscale || aligned16(nscale))) {
         const long long steps = (M * C4 + 255) / 256;
-        BY_DT(dt, (bn_bwd_apply_rows_kernel<T><<<(unsigned)(steps < 2048 ? (steps < 1 ? 1 : steps) : 2048), 256, 0, st>>>(b)));
+        BY_DT(dt, (bn_bwd_apply_rows_kernel<T><<<rows_grid(steps), 256, 0, st>>>(b)));
     } else {
         BY_DT(dt, (bn_bwd_apply_kernel<T><<<grid_for(M * (C / 4)), 256, 0, st>>>(b)));
     }
