@@ -17,6 +17,7 @@
 #include "metric_kernels.h"
 #include "optim_kernels.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -60,6 +61,7 @@ Switch g_sw_pair("ERFNET_NO_PAIR"), g_sw_wgrad_line("ERFNET_NO_WGRAD_LINE"), g_s
 // off by default: measured 5-12 % slower than two conv16_kernel launches (both are issue-bound, not
 // memory-bound, at 16 channels); ERFNET_PAIR16=1 or ERF_OPT_PAIR16 turns it on
 Switch g_sw_pair16("ERFNET_PAIR16", 0);
+Switch g_sw_conv16_rows("ERFNET_NO_CONV16_ROWS");      // ERF_OPT_CONV16_ROWS
 std::atomic<int> g_line2{1};        // ERF_OPT_LINE2
 // fp32 64 / 128-channel 1-D convolutions on the bf16 matrix pipe, operands split in three bf16 terms
 // (line_x3_kernel, wgrad_line_x3_kernel): fp32 accuracy at 2.7x the fp32 matrix rate.
@@ -563,6 +565,22 @@ int run_igemm_t(const IgemmDesc &d, hipStream_t st)
             static int no16 = -1;
             if (no16 < 0) { const char *e = getenv("ERFNET_NO_CONV16_BF16"); no16 = (e && atoi(e)) ? 1 : 0; }
             if (!no16 && d.in_C % 8 == 0 && d.in_coff % 8 == 0 && aligned16(d.in)) {
+                // rows variant: tiles of 16 pixels never leave an image row, taps along one axis only
+                const bool norows = !g_sw_conv16_rows.on();
+                const bool same = d.in_H == d.GH && d.in_W == d.GW && d.out_H == d.GH && d.out_W == d.GW;
+                const bool aw = d.tdh[0] == 0 && d.tdh[1] == 0 && d.tdh[2] == 0;
+                const bool ah = d.tdw[0] == 0 && d.tdw[1] == 0 && d.tdw[2] == 0;
+                const long long widest = M * (long long)std::max(std::max(d.in_C, d.out_C), std::max(d.epi.res ? d.epi.res_C : 0, d.epi.mask ? d.epi.mask_C : 0)) * 2;
+                if (!norows && same && (aw || ah) && d.GW % 16 == 0 && widest < (1LL << 31) &&
+                    d.out_C % 4 == 0 && d.out_coff % 4 == 0 && aligned16(d.out) &&
+                    (!d.epi.res || (d.epi.res_C % 4 == 0 && d.epi.res_coff % 4 == 0 && aligned16(d.epi.res))) &&
+                    (!d.epi.mask || (d.epi.mask_C % 4 == 0 && d.epi.mask_coff % 4 == 0 && aligned16(d.epi.mask)))) {
+                    const unsigned blocks = (unsigned)((M + 1023) / 1024);
+                    if (aw) conv16_bf16_rows_kernel<8, 2, true><<<blocks, 256, 0, st>>>(d);
+                    else conv16_bf16_rows_kernel<8, 2, false><<<blocks, 256, 0, st>>>(d);
+                    CHECK_LAUNCH("conv16_bf16_rows_kernel");
+                    return 0;
+                }
                 if (grp >= 2) conv16_bf16_kernel<8, 2><<<(unsigned)((M + 1023) / 1024), 256, 0, st>>>(d);
                 else conv16_bf16_kernel<8, 1><<<(unsigned)((M + 511) / 512), 256, 0, st>>>(d);
                 CHECK_LAUNCH("conv16_bf16_kernel");
@@ -1534,6 +1552,7 @@ int erf_set_option(int option, int value)
     if (option == ERF_OPT_STREAM16) return g_sw_stream16.set(value);
     if (option == ERF_OPT_PAIR16) return g_sw_pair16.set(value);
     if (option == ERF_OPT_LINE2) return g_line2.exchange(value ? 1 : 0);
+    if (option == ERF_OPT_CONV16_ROWS) return g_sw_conv16_rows.set(value);
     if (option == ERF_OPT_SPLIT_BF16) {
         const int prev = x3_mode();
         g_x3_mode.store(value < 0 ? 0 : (value > 2 ? 2 : value), std::memory_order_relaxed);

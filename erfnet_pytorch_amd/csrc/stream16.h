@@ -9,6 +9,7 @@
 // MFMA 16x16x4 layouts (lane l: i = l & 15, g = l >> 4):
 //   A[16][4]: lane holds A[i][g];  B[4][16]: lane holds B[g][i];  D[16][16]: reg r = D[4g + r][i].
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 // The 16x16x3 weights of a 16-channel convolution, staged once per block: every lane needs 12-16 of
@@ -557,6 +558,158 @@ __global__ __launch_bounds__(256) void conv16_bf16_kernel(const IgemmDesc d)
             }
             if (opix[u] >= 0)
                 Act<T>::st4(d.out, (long long)((unsigned)opix[u] * d.out_C + d.out_coff + 4 * g), v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv16_bf16_kernel for images whose width is a multiple of 16 (every 16-channel layer of the
+// networks at even input sizes): a tile of 16 pixels then never leaves its image row, so image, row
+// and first column of a tile are wave-uniform and live in scalar registers, and a lane's share of
+// every address is a constant formed once per wave.  PMC showed the general kernel bound by vector
+// instruction issue (about 106 VALU instructions per tile and lane, half of them coordinates, wrap
+// tests and 64-bit store addresses; VALU busy on every SIMD for half the kernel's duration): here a
+// tile costs one addition per operand load, one bounds test per tap load, and the epilogue.
+//   AW: the taps shift along the row (a lane's column decides whether its tap is inside the image);
+//   otherwise along the column (the lane's tap row decides).
+// Residual / mask / dropout factors / output go through buffer accesses with the tile's byte offset
+// as the scalar offset: absent tensors have empty descriptors (loads return zero), a tile beyond the
+// end presents an out-of-range offset (loads return zero, the store is dropped).
+template <int U, int G, bool AW>
+__global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned W = (unsigned)d.GW, H = (unsigned)d.GH;
+    const unsigned M = (unsigned)d.N * H * W, GHW = H * W;
+    const unsigned base0 = ((unsigned)blockIdx.x * 4 + wave) * (16 * U * G);
+    __shared__ float wlds[768];
+    const float *wsrc = stage_w16(d, wlds);
+    if (base0 >= M) return;
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, M * d.in_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, M * d.out_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, d.epi.res ? M * d.epi.res_C * 2u : 0u);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, d.epi.mask ? M * d.epi.mask_C * 2u : 0u);
+    const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, d.epi.nscale ? (unsigned)d.N * 64u : 0u);
+    const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
+    const bool has_ns = d.epi.nscale != nullptr, has_mask = d.epi.mask != nullptr;
+
+    // weight operands: lane (j = i, g) holds Wt[j][k = 8g..8g+7]; second instruction: tap 2, upper k zero
+    bf16x8 wa, wb;
+    {
+        const int t = g >> 1, c0 = 8 * (g & 1);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wa[e] = (__bf16)wsrc[d.woff[t] + (c0 + e) * d.wsk + i * d.wsn];
+            const float w2 = wsrc[d.woff[2] + (c0 + e) * d.wsk + i * d.wsn];
+            wb[e] = (__bf16)(g < 2 ? w2 : 0.0f);
+        }
+    }
+    // a lane's constant part of every byte offset (relative to the tile's first pixel); the tap loads
+    // may reach backwards: their sum with the tile's offset is formed per tile and is non-negative
+    // whenever the tap lies inside the image
+    const int dh1 = d.tdh[g >> 1], dw1 = d.tdw[g >> 1], dh2 = d.tdh[2], dw2 = d.tdw[2];
+    const int c8 = d.in_coff + 8 * (g & 1);
+    const int lane_in1 = ((dh1 * (int)W + dw1 + i) * d.in_C + c8) * 2;
+    const int lane_in2 = ((dh2 * (int)W + dw2 + i) * d.in_C + c8) * 2;
+    // the coordinate the bounds test looks at, relative to the tile: column (AW) or row; lanes g >= 2
+    // load nothing with the second instruction: their coordinate always fails
+    const int rel1 = AW ? i + dw1 : dh1;
+    const int rel2 = g >= 2 ? 0x40000000 : (AW ? i + dw2 : dh2);
+    const unsigned lane_res = (unsigned)((i * d.epi.res_C + d.epi.res_coff + 4 * g) * 2);
+    const unsigned lane_mask = (unsigned)((i * d.epi.mask_C + d.epi.mask_coff + 4 * g) * 2);
+    const unsigned lane_out = (unsigned)((i * d.out_C + d.out_coff + 4 * g) * 2);
+    const unsigned res_px = (unsigned)d.epi.res_C * 2u, mask_px = (unsigned)d.epi.mask_C * 2u;
+    const unsigned in_px = (unsigned)d.in_C * 2u, out_px = (unsigned)d.out_C * 2u;
+    // an absent mask reads as zero: compare against -inf then, so every element passes
+    const float mask_thr = has_mask ? 0.0f : -__builtin_inff();
+
+    unsigned tn = base0 / GHW;
+    unsigned trem = base0 - tn * GHW;
+    unsigned tgi = trem / W, tgj = trem - tgi * W;
+    f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    f32x4 sh = buf_load4(r_bias, g * 16u);
+    if (d.epi.bn.on) {          // wave-uniform
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(d.epi.bn.gamma + 4 * g);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(d.epi.bn.beta + 4 * g);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(d.epi.bn.mean + 4 * g);
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(d.epi.bn.var + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = d.epi.bn.var_is_invstd ? va[r] : rsqrtf(va[r] + d.epi.bn.eps);
+            sc[r] = ga[r] * inv;
+            sh[r] = (sh[r] - mu[r]) * sc[r] + be[r];
+        }
+    }
+    const bool relu = d.epi.relu != 0;
+
+    for (int grp = 0; grp < G; ++grp) {
+        const unsigned base = base0 + grp * (16 * U);
+        if (base >= M) break;
+        u32x4 x1[U], x2[U];
+        u32x2 qres[U], qmask[U];
+        f32x4 rns[U];
+        unsigned opix[U];           // pixel index of the tile's first pixel | ERF_OOB beyond the end
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // wave-uniform: the tile's first pixel, its row / column, and whether the tile exists
+            const bool live = base + u * 16 < M;
+            const unsigned px0 = (tn * H + tgi) * W + tgj;
+            const unsigned lim = live ? (AW ? W : H) : 0u;          // a dead tile fails every bounds test
+            const unsigned pos = AW ? tgj : tgi;
+            const unsigned in0 = px0 * in_px;
+            const unsigned o1 = (pos + (unsigned)rel1) < lim ? in0 + (unsigned)lane_in1 : ERF_OOB;
+            const unsigned o2 = (pos + (unsigned)rel2) < lim ? in0 + (unsigned)lane_in2 : ERF_OOB;
+            x1[u] = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)o1, 0, 0);
+            x2[u] = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)o2, 0, 0);
+            const unsigned dead = live ? 0u : ERF_OOB;
+            opix[u] = px0 | dead;
+            qres[u] = __builtin_amdgcn_raw_buffer_load_b64(r_res, (int)(lane_res | dead), (int)(px0 * res_px), 0);
+            qmask[u] = __builtin_amdgcn_raw_buffer_load_b64(r_mask, (int)(lane_mask | dead), (int)(px0 * mask_px), 0);
+            rns[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_ns, (int)(16u * g), (int)(tn * 64u), 0));
+            tgj += 16;                                   // uniform advance to the next tile
+            if (tgj >= W) {
+                tgj = 0;
+                if (++tgi == H) { tgi = 0; ++tn; }
+            }
+        }
+        f32x4 acc[U];
+        const f32x4 zero = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1[u]), zero, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, __builtin_bit_cast(bf16x8, x2[u]), acc[u], 0, 0, 0);
+        // epilogue specialised on the wave-uniform switches (selects per element otherwise)
+        auto finish = [&](auto relu_t, auto ns_t) __attribute__((always_inline)) {
+            constexpr bool RELU = decltype(relu_t)::value, NS = decltype(ns_t)::value;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f32x4 rres = unpack_bf16x4(qres[u]), rmask = unpack_bf16x4(qmask[u]);
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = acc[u][r] * sc[r] + sh[r];
+                    if (NS) e *= rns[u][r];
+                    e += rres[r];
+                    if (RELU) e = fmaxf(e, 0.0f);
+                    v[r] = rmask[r] > mask_thr ? e : 0.0f;
+                }
+                const unsigned dead = opix[u] & ERF_OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), r_out, (int)(lane_out | dead),
+                                                      (int)((opix[u] & ~ERF_OOB) * out_px), 0);
+            }
+        };
+        using T1 = std::true_type;
+        using T0 = std::false_type;
+        if (relu) {
+            if (has_ns) finish(T1{}, T1{});
+            else finish(T1{}, T0{});
+        } else {
+            if (has_ns) finish(T0{}, T1{});
+            else finish(T0{}, T0{});
         }
     }
 }

@@ -78,6 +78,10 @@ unsigned long long erf_launch_count(void);
  * 0 = the fp32-MFMA kernels (pair_f32_kernel, wgrad_line_kernel).  The paths agree to fp32 rounding.
  * Non-finite inputs give NaN on the split path. */
 #define ERF_OPT_SPLIT_BF16 6
+/* ERF_OPT_CONV16_ROWS (default 1; ERFNET_NO_CONV16_ROWS=1): bf16 16-channel 1-D convolutions on images
+ * whose width is a multiple of 16 take the kernel that keeps a tile's coordinates in scalar registers
+ * (conv16_bf16_rows_kernel); off = the general kernel.  Same results bit for bit. */
+#define ERF_OPT_CONV16_ROWS 7
 int erf_set_option(int option, int value);
 
 /* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block

@@ -414,3 +414,40 @@ def test_eight_wave_pair_kernel_in_a_training_step_is_bit_identical():
         _lib.set_option(_lib.OPT_LINE2, prev)
     for i, (u, v) in enumerate(zip(ref, got)):
         assert torch.equal(u, v), i
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 10, 48), (3, 5, 16), (1, 7, 32), (2, 33, 64)])
+def test_conv16_rows_kernel_equals_general_kernel(n, h, w):
+    """16-channel non_bottleneck_1d (the decoder's last stage, train/erfnet_blocks.py:33-73) on bf16
+    tensors whose width is a multiple of 16: the kernel with scalar tile coordinates
+    (ERF_OPT_CONV16_ROWS) against the general one — forward, input gradient and weight gradients bit
+    for bit; sizes that leave whole tiles beyond the end, one tile per row, several rows per wave."""
+    from erfnet_pytorch_amd import _lib
+    from erfnet_pytorch_amd.erfnet_blocks import non_bottleneck_1d
+    torch.manual_seed(5)
+    blk = non_bottleneck_1d(16, 0.0, 1).to(DEV).train()
+    x0 = _nhwc(torch.randn(n, 16, h, w, device=DEV).to(BF))
+    gy = _nhwc(torch.randn(n, 16, h, w, device=DEV).to(BF))
+    outs = {}
+    for rows in (0, 1):
+        prev = _lib.set_option(_lib.OPT_CONV16_ROWS, rows)
+        try:
+            for p in blk.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            n0 = _lib.launch_count()
+            y = blk(x)
+            y.backward(gy)
+            assert _lib.launch_count() > n0
+            torch.cuda.synchronize()
+            outs[rows] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()
+                                                                 if p.grad is not None]
+        finally:
+            _lib.set_option(_lib.OPT_CONV16_ROWS, prev)
+    assert len(outs[0]) == len(outs[1]) > 6
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # and against the same block on fp32 tensors
+    xf = x0.float().clone().requires_grad_(True)
+    yf = blk(xf)
+    _check(outs[1][0], yf.detach(), "rows forward against fp32", tol=2e-2)
