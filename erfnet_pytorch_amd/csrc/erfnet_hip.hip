@@ -575,9 +575,15 @@ int run_igemm_t(const IgemmDesc &d, hipStream_t st)
                     d.out_C % 4 == 0 && d.out_coff % 4 == 0 && aligned16(d.out) &&
                     (!d.epi.res || (d.epi.res_C % 4 == 0 && d.epi.res_coff % 4 == 0 && aligned16(d.epi.res))) &&
                     (!d.epi.mask || (d.epi.mask_C % 4 == 0 && d.epi.mask_coff % 4 == 0 && aligned16(d.epi.mask)))) {
-                    const unsigned blocks = (unsigned)((M + 1023) / 1024);
-                    if (aw) conv16_bf16_rows_kernel<8, 2, true><<<blocks, 256, 0, st>>>(d);
-                    else conv16_bf16_rows_kernel<8, 2, false><<<blocks, 256, 0, st>>>(d);
+                    if (grp >= 2) {
+                        const unsigned blocks = (unsigned)((M + 1023) / 1024);
+                        if (aw) conv16_bf16_rows_kernel<8, 2, true><<<blocks, 256, 0, st>>>(d);
+                        else conv16_bf16_rows_kernel<8, 2, false><<<blocks, 256, 0, st>>>(d);
+                    } else {
+                        const unsigned blocks = (unsigned)((M + 511) / 512);
+                        if (aw) conv16_bf16_rows_kernel<8, 1, true><<<blocks, 256, 0, st>>>(d);
+                        else conv16_bf16_rows_kernel<8, 1, false><<<blocks, 256, 0, st>>>(d);
+                    }
                     CHECK_LAUNCH("conv16_bf16_rows_kernel");
                     return 0;
                 }

@@ -573,8 +573,8 @@ __global__ __launch_bounds__(256) void conv16_bf16_kernel(const IgemmDesc d)
 //   AW: the taps shift along the row (a lane's column decides whether its tap is inside the image);
 //   otherwise along the column (the lane's tap row decides).
 // Residual / mask / dropout factors / output go through buffer accesses with the tile's byte offset
-// as the scalar offset: absent tensors have empty descriptors (loads return zero), a tile beyond the
-// end presents an out-of-range offset (loads return zero, the store is dropped).
+// as the scalar offset: absent tensors are skipped with wave-uniform branches, a tile beyond the end
+// presents an out-of-range offset (loads return zero, the store is dropped).
 template <int U, int G, bool AW>
 __global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d)
 {
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d
     const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, d.epi.mask ? M * d.epi.mask_C * 2u : 0u);
     const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, d.epi.nscale ? (unsigned)d.N * 64u : 0u);
     const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
-    const bool has_ns = d.epi.nscale != nullptr, has_mask = d.epi.mask != nullptr;
+    const bool has_ns = d.epi.nscale != nullptr, has_mask = d.epi.mask != nullptr, has_res = d.epi.res != nullptr;
 
     // weight operands: lane (j = i, g) holds Wt[j][k = 8g..8g+7]; second instruction: tap 2, upper k zero
     bf16x8 wa, wb;
@@ -622,8 +622,6 @@ __global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d
     const unsigned lane_out = (unsigned)((i * d.out_C + d.out_coff + 4 * g) * 2);
     const unsigned res_px = (unsigned)d.epi.res_C * 2u, mask_px = (unsigned)d.epi.mask_C * 2u;
     const unsigned in_px = (unsigned)d.in_C * 2u, out_px = (unsigned)d.out_C * 2u;
-    // an absent mask reads as zero: compare against -inf then, so every element passes
-    const float mask_thr = has_mask ? 0.0f : -__builtin_inff();
 
     unsigned tn = base0 / GHW;
     unsigned trem = base0 - tn * GHW;
@@ -665,9 +663,13 @@ __global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d
             x2[u] = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)o2, 0, 0);
             const unsigned dead = live ? 0u : ERF_OOB;
             opix[u] = px0 | dead;
-            qres[u] = __builtin_amdgcn_raw_buffer_load_b64(r_res, (int)(lane_res | dead), (int)(px0 * res_px), 0);
-            qmask[u] = __builtin_amdgcn_raw_buffer_load_b64(r_mask, (int)(lane_mask | dead), (int)(px0 * mask_px), 0);
-            rns[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_ns, (int)(16u * g), (int)(tn * 64u), 0));
+            // absent tensors are skipped with wave-uniform branches, as in conv16_bf16_kernel
+            qres[u] = u32x2{0u, 0u};
+            qmask[u] = u32x2{0x3f803f80u, 0x3f803f80u};          // four bf16 ones
+            rns[u] = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+            if (has_res) qres[u] = __builtin_amdgcn_raw_buffer_load_b64(r_res, (int)(lane_res | dead), (int)(px0 * res_px), 0);
+            if (has_mask) qmask[u] = __builtin_amdgcn_raw_buffer_load_b64(r_mask, (int)(lane_mask | dead), (int)(px0 * mask_px), 0);
+            if (has_ns) rns[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_ns, (int)(16u * g), (int)(tn * 64u), 0));
             tgj += 16;                                   // uniform advance to the next tile
             if (tgj >= W) {
                 tgj = 0;
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d
                     if (NS) e *= rns[u][r];
                     e += rres[r];
                     if (RELU) e = fmaxf(e, 0.0f);
-                    v[r] = rmask[r] > mask_thr ? e : 0.0f;
+                    v[r] = rmask[r] > 0.0f ? e : 0.0f;
                 }
                 const unsigned dead = opix[u] & ERF_OOB;
                 __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), r_out, (int)(lane_out | dead),
