@@ -45,8 +45,10 @@ FWD_GFLOP_PER_IMAGE, FWD_MB_PER_IMAGE_F32 = 53.2, 341.8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: a timed region of about half a second (50 steps of 8-9 ms) so that run-to-run noise
+    # stays well under one per cent
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="images per GPU")
     ap.add_argument("--model", default="net_classification",
                     choices=["net_classification", "erfnet_bn"],
