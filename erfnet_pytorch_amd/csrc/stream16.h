@@ -676,17 +676,20 @@ __global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d
                 if (++tgi == H) { tgi = 0; ++tn; }
             }
         }
-        f32x4 acc[U];
-        const f32x4 zero = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1[u]), zero, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, __builtin_bit_cast(bf16x8, x2[u]), acc[u], 0, 0, 0);
-        // epilogue specialised on the wave-uniform switches (selects per element otherwise)
+        // The products and the epilogue form ONE basic block per specialisation: an fp32 transcription
+        // of this kernel with a branch between the last MFMA and the first read of its result returned
+        // stale accumulator values in pixels 12-15 of a tile, and was right with the products inside
+        // the specialised block (the bf16 form was bit-identical to the general kernel either way).
         auto finish = [&](auto relu_t, auto ns_t) __attribute__((always_inline)) {
             constexpr bool RELU = decltype(relu_t)::value, NS = decltype(ns_t)::value;
+            f32x4 acc[U];
+            const f32x4 zero = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(bf16x8, x1[u]), zero, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, __builtin_bit_cast(bf16x8, x2[u]), acc[u], 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const f32x4 rres = unpack_bf16x4(qres[u]), rmask = unpack_bf16x4(qmask[u]);
