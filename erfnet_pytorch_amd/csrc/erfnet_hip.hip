@@ -893,7 +893,21 @@ int launch_reduce_batch(const WgradDesc *d, int n, float *const *dw, float *cons
         for (int t = 0; t < d[i].ntaps; ++t) r.woff[t] = woff[t];
         r.wsk = wsk; r.wsn = wsn; r.bias_taps = bias_taps;
     }
-    const long long tot = (long long)d[0].ntaps * d[0].K * d[0].Nout + d[0].Nout;
+    const long long nw = (long long)d[0].ntaps * d[0].K * d[0].Nout;
+    const long long tot = nw + d[0].Nout;
+    // 16-byte slab reads where every slab of the batch allows them (ERFNET_NO_REDUCE4=1: scalar kernel)
+    static int no4 = -1;
+    if (no4 < 0) { const char *e = getenv("ERFNET_NO_REDUCE4"); no4 = (e && atoi(e)) ? 1 : 0; }
+    bool vec = !no4 && d[0].Nout % 4 == 0;
+    for (int i = 0; i < n && vec; ++i)
+        vec = d[i].K == d[0].K && d[i].Nout == d[0].Nout && d[i].ntaps == d[0].ntaps && aligned16(d[i].partial) &&
+              ((long long)d[i].ntaps * d[i].K * d[i].Nout + (long long)d[i].ntaps * d[i].Nout) % 4 == 0;
+    if (vec) {
+        const int wblocks = (int)((nw + 127) / 128), bblocks = (d[0].Nout + 31) / 32;
+        reduce_partials4_kernel<<<dim3((unsigned)(wblocks + bblocks), n, 1), 256, 0, st>>>(rb, wblocks);
+        CHECK_LAUNCH("reduce_partials4_kernel");
+        return 0;
+    }
     reduce_partials_kernel<<<dim3((unsigned)((tot + 31) / 32), n, 1), 256, 0, st>>>(rb);
     CHECK_LAUNCH("reduce_partials_kernel");
     return 0;

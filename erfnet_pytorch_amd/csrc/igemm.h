@@ -548,3 +548,69 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceBatch 
         d.db[idx - nw] = tot;
     }
 }
+
+// The same reduction with 16-byte slab reads for slabs whose weight part and length are multiples of
+// four floats (every 16 / 64 / 128-channel layer): a thread owns four consecutive elements, its
+// slab group's loads are issued eight at a time, and the additions run in reduce_partials_kernel's
+// order (slabs g, g+8, ... of a group one after the other, then the eight groups), so the results
+// are bit-identical.  Blocks [0, wblocks) cover the weight part (128 elements each), the blocks
+// behind them the bias elements with the scalar code.
+__global__ __launch_bounds__(256) void reduce_partials4_kernel(const ReduceBatch batch, int wblocks)
+{
+    const ReduceDesc &d = batch.r[blockIdx.y];
+    const long long nw = (long long)d.ntaps * d.K * d.Nout;
+    const long long slab = nw + (long long)d.ntaps * d.Nout + d.tail;
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    if ((int)blockIdx.x < wblocks) {
+        __shared__ f32x4 red4[8][33];
+        const long long idx = ((long long)blockIdx.x * 32 + e) * 4;
+        f32x4 s = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (idx < nw) {
+            const float *src = d.partial + idx;
+            int i = g;
+            for (; i + 56 < d.nsplit; i += 64) {                // eight slabs of this group per trip
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(src + (long long)(i + 8 * u) * slab);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = s + v[u];
+            }
+            for (; i < d.nsplit; i += 8) s = s + *reinterpret_cast<const f32x4 *>(src + (long long)i * slab);
+        }
+        red4[g][e] = s;
+        __syncthreads();
+        if (g != 0 || idx >= nw) return;
+        f32x4 tot = red4[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) tot = tot + red4[k][e];
+        const int j = (int)(idx % d.Nout);                      // Nout % 4 == 0: the four share k and t
+        const int k = (int)((idx / d.Nout) % d.K);
+        const int t = (int)(idx / ((long long)d.Nout * d.K));
+        float *dst = d.dw + d.woff[t] + (long long)k * d.wsk + (long long)j * d.wsn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[(long long)q * d.wsn] = tot[q];
+        return;
+    }
+    __shared__ float red[8][33];
+    const int nb = d.kside ? d.K : d.Nout;
+    const int j = ((int)blockIdx.x - wblocks) * 32 + e;
+    float s = 0.0f;
+    if (j < nb) {
+        if (d.kside) {
+            const long long off = nw + (long long)d.ntaps * d.Nout + j;
+            for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + off];
+        } else {
+            for (int t = 0; t < d.ntaps; ++t) {
+                if (!((d.bias_taps >> t) & 1u)) continue;
+                for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + nw + (long long)t * d.Nout + j];
+            }
+        }
+    }
+    red[g][e] = s;
+    __syncthreads();
+    if (g != 0 || j >= nb || !d.db) return;
+    float tot = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) tot += red[k][e];
+    d.db[j] = tot;
+}
