@@ -1,4 +1,4 @@
-"""sha1 over every parameter gradient of one training step on fixed inputs (`grad_hash.py [f32|bf16] [model]`):
+"""sha1 over every parameter gradient of one training step on fixed inputs (`grad_hash.py [f32|bf16] [model] [N H W]`):
 two runs that print the same digest computed bit-identical gradients (A/B of kernel switches)."""
 import hashlib
 import os
@@ -16,8 +16,9 @@ bn = len(sys.argv) > 2 and sys.argv[2] == "erfnet_bn"
 torch.manual_seed(0)
 net = (erfnet.ERFNet(20) if bn else net_classification.Net(softmax_classes=20)).to(DEV).train()
 g = torch.Generator().manual_seed(7)
-x = torch.rand(3, 3, 256, 512, generator=g).to(DEV).to(dt)
-lab = torch.randint(-1, 20, (3, 256, 512), generator=g).to(DEV)
+N, H, W = (int(a) for a in sys.argv[3:6]) if len(sys.argv) > 5 else (3, 256, 512)
+x = torch.rand(N, 3, H, W, generator=g).to(DEV).to(dt)
+lab = torch.randint(-1, 20, (N, H, W), generator=g).to(DEV)
 out = net(x)
 out = out[0] if isinstance(out, tuple) else out
 loss = CrossEntropyLoss2d()(out, lab)
