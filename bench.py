@@ -58,7 +58,82 @@ def parse():
                     help="storage type of the activations (parameters and their gradients stay fp32)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (bf16 rates, harnesses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as child processes even for --gpus 1 (for --gpus N > 1 without a "
+                         "launcher's WORLD_SIZE in the environment this is what happens anyway)")
     return ap.parse_args()
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(nranks, child_cmd, ndev, out=None, poll_s=0.2):
+    """One command, all GPUs (what train/main.py:869-874 gets from torch.nn.DataParallel): start
+    `nranks` fresh child processes running `child_cmd`, one per device, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relay rank 0's standard output line by line to `out`,
+    and return the first non-zero exit code of any child (0 if all succeed).  The caller must not
+    have touched the GPU: the children are fresh processes (never an exec of this one), and this
+    parent only waits.  A child that fails ends the others (by their exact PIDs)."""
+    import subprocess
+    import threading
+    out = out or sys.stdout
+    if nranks < 1:
+        raise ValueError("need at least one rank")
+    if nranks > ndev:
+        print(f"bench.py: --gpus {nranks} but only {ndev} GPU(s) are visible; one device per rank is needed",
+              file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(nranks),
+                    "LOCAL_WORLD_SIZE": str(nranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port,
+                    "ERFNET_BENCH_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(list(child_cmd), env=env, stdout=subprocess.PIPE, text=True, bufsize=1))
+
+    def relay(proc, sink):
+        for line in proc.stdout:
+            sink.write(line)
+            sink.flush()
+    threads = [threading.Thread(target=relay, args=(p, out if r == 0 else sys.stderr), daemon=True)
+               for r, p in enumerate(procs)]
+    for t in threads:
+        t.start()
+    code = 0
+    live = set(range(nranks))
+    kill_at = None                      # a rank that ignores SIGTERM (stuck in a collective) is killed
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 128 - rc
+                print(f"bench.py: rank {r} exited with {rc}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+                kill_at = time.monotonic() + 20.0
+        if live and kill_at is not None and time.monotonic() > kill_at:
+            for q in live:
+                procs[q].kill()
+            kill_at = None
+        if live:
+            time.sleep(poll_s)
+    for r, p in enumerate(procs):
+        try:
+            p.wait(timeout=30)
+        except Exception:
+            p.kill()
+    for t in threads:
+        t.join(timeout=10)
+    return code
 
 
 def build_model(name):
@@ -355,6 +430,11 @@ def cpu_baseline():
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        # No launcher above us: be the launcher.  Nothing here initialises the GPU
+        # (torch.cuda.device_count() only counts), the ranks are fresh child processes.
+        child = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--spawn"]
+        sys.exit(launch_ranks(args.gpus, child, torch.cuda.device_count()))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
