@@ -9,6 +9,7 @@
 #include "line_bf16.h"
 #include "line2_bf16.h"
 #include "line_x3.h"
+#include "line_x3r.h"
 #include "igemm_bf16.h"
 #include "wgrad_line.h"
 #include "wgrad_line_bf16.h"
@@ -62,6 +63,9 @@ Switch g_sw_pair("ERFNET_NO_PAIR"), g_sw_wgrad_line("ERFNET_NO_WGRAD_LINE"), g_s
 // memory-bound, at 16 channels); ERFNET_PAIR16=1 or ERF_OPT_PAIR16 turns it on
 Switch g_sw_pair16("ERFNET_PAIR16", 0);
 Switch g_sw_conv16_rows("ERFNET_NO_CONV16_ROWS");      // ERF_OPT_CONV16_ROWS
+// the split-bf16 convolutions on the rolling kernel (line_x3r_kernel: every input line split once
+// instead of once per tap); ERFNET_NO_X3R=1 / ERF_OPT_X3_ROLL = 0 keeps line_x3_kernel
+Switch g_sw_x3r("ERFNET_NO_X3R");
 std::atomic<int> g_line2{1};        // ERF_OPT_LINE2
 // fp32 64 / 128-channel 1-D convolutions on the bf16 matrix pipe, operands split in three bf16 terms
 // (line_x3_kernel, wgrad_line_x3_kernel): fp32 accuracy at 2.7x the fp32 matrix rate.
@@ -308,6 +312,18 @@ int run_line_x3(LineDesc ld, int NC, hipStream_t st)
     if (ntiles <= 0) return 0;
     const int slots = line_x3_slots(NC);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
+    {   // the rolling kernel: 64-pixel tiles, taps {-dil, 0, +dil} (either order), whole chains per image
+        const int dil = ld.s1[0] < 0 ? -ld.s1[0] : ld.s1[0];
+        static int only = -1;       // ERFNET_X3R_ONLY=64 / 128: the rolling kernel for that width only (experiments)
+        if (only < 0) { const char *e = getenv("ERFNET_X3R_ONLY"); only = e ? atoi(e) : 0; }
+        if (g_sw_x3r.on() && !ld.stats && BM == 64 && dil > 0 && ld.s1[1] == 0 && ld.s1[2] == -ld.s1[0] &&
+            ld.lines_per_img % dil == 0 && (!only || only == NC)) {
+            if (NC == 128) line_x3r_kernel<128, 64><<<grid, 256, 0, st>>>(ld);
+            else line_x3r_kernel<64, 64><<<grid, 256, 0, st>>>(ld);
+            CHECK_LAUNCH("line_x3r_kernel");
+            return 0;
+        }
+    }
 #define X3_LAUNCH(nc, bm)                                                                           \
     do {                                                                                            \
         if (ld.stats) line_x3_kernel<nc, bm, true><<<grid, 256, 0, st>>>(ld);                       \
@@ -1573,6 +1589,7 @@ int erf_set_option(int option, int value)
     if (option == ERF_OPT_PAIR16) return g_sw_pair16.set(value);
     if (option == ERF_OPT_LINE2) return g_line2.exchange(value ? 1 : 0);
     if (option == ERF_OPT_CONV16_ROWS) return g_sw_conv16_rows.set(value);
+    if (option == ERF_OPT_X3_ROLL) return g_sw_x3r.set(value);
     if (option == ERF_OPT_SPLIT_BF16) {
         const int prev = x3_mode();
         g_x3_mode.store(value < 0 ? 0 : (value > 2 ? 2 : value), std::memory_order_relaxed);

@@ -82,6 +82,10 @@ unsigned long long erf_launch_count(void);
  * whose width is a multiple of 16 take the kernel that keeps a tile's coordinates in scalar registers
  * (conv16_bf16_rows_kernel); off = the general kernel.  Same results bit for bit. */
 #define ERF_OPT_CONV16_ROWS 7
+/* ERF_OPT_X3_ROLL (default 1; ERFNET_NO_X3R=1): the split-bf16 convolutions of ERF_OPT_SPLIT_BF16 on the
+ * rolling kernel (an input line is split into its bf16 terms once and serves three output lines)
+ * instead of once per tap. */
+#define ERF_OPT_X3_ROLL 8
 int erf_set_option(int option, int value);
 
 /* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block
