@@ -31,7 +31,7 @@ import torch
 import torch.distributed as dist
 
 PER_GPU_BATCH, HEIGHT, WIDTH, CLASSES = 6, 512, 1024, 20
-# dominant kernel of the fp32 step: a 1-D convolution at the 128-channel stage
+# shape of the 128-channel stage (the bf16 dominant kernel's)
 DOM_C, DOM_H, DOM_W = 128, HEIGHT // 8, WIDTH // 8
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X v_mfma_f32_32x32x2_f32 peak (= fp32 vector peak)
 BF16_MATRIX_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
@@ -166,62 +166,92 @@ def event_time_ms(fn, device, reps, warm=5):
     return start.elapsed_time(stop) / reps
 
 
-def dominant_kernel_roofline(device, batch):
-    """line_x3_kernel<128,64> — one 3-tap 1-D convolution 128 -> 128 channels over batch x 64 x 128
-    pixels (the (3,1) convolution with dilation 2 and ReLU of a non_bottleneck_1d) — is the kernel the
-    fp32 training step spends most of its time in (its 64-channel variant takes as much).  It forms
-    every fp32 product from three bf16 terms per operand (six bf16 MFMAs per k-step, fp32
-    accumulation), so its ceiling is the dense bf16 matrix peak / 6.  erf_conv_line_forward_split
-    issues exactly one such launch per call (weights are packed once, outside the timed region);
-    algorithmic FLOPs per launch = 2 * pixels * (3*128) * 128, algorithmic bytes = input read + output
-    written."""
+def step_share(kernel_prefix):
+    """Share of the fp32 training step's kernel time spent in kernels whose name starts with
+    `kernel_prefix`, from the committed rocprofv3 --kernel-trace --stats summary of the step."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r3_train_f32_kernel_stats.csv")
+    if not os.path.exists(path):
+        return None
+    try:
+        rows = list(csv.DictReader(open(path)))
+        total = sum(float(r["TotalDurationNs"]) for r in rows)
+        mine = sum(float(r["TotalDurationNs"]) for r in rows if r["Name"].replace("void ", "").startswith(kernel_prefix))
+        return round(mine / total, 4) if total else None
+    except Exception:
+        return None
+
+
+def line_conv_roofline(device, batch, c, div, dil):
+    """One launch of line_x3r_kernel<c,64>: a 3-tap 1-D convolution c -> c channels ((3,1), dilation
+    `dil`, + bias + ReLU: the first convolution of a non_bottleneck_1d) over batch x H/div x W/div pixels
+    of fp32 NHWC tensors.  Every fp32 product is formed from three bf16 terms per operand (six bf16
+    MFMAs per k-step, fp32 accumulation), so the matrix ceiling is the dense bf16 peak / 6; the memory
+    floor is input read + output written once.  erf_conv_line_forward_split issues exactly one such
+    launch per call (weights are packed once, outside the timed region)."""
     from erfnet_pytorch_amd import functional as hipf
+    h, w_ = HEIGHT // div, WIDTH // div
     g = torch.Generator(device="cpu").manual_seed(3)
-    x = torch.randn(batch, DOM_C, DOM_H, DOM_W, generator=g).clamp_(min=0).to(device)
+    x = torch.randn(batch, c, h, w_, generator=g).clamp_(min=0).to(device)
     x = x.contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(DOM_C, DOM_C, 3, 1, generator=g) * 0.05).to(device)
-    b = torch.zeros(DOM_C, device=device)
+    w = (torch.randn(c, c, 3, 1, generator=g) * 0.05).to(device)
+    b = torch.zeros(c, device=device)
     packed = hipf.conv_line_pack_split(w)
-    ms = event_time_ms(lambda: hipf.conv_line_split(x, packed, b, 0, 2, True), device, 50)
-    pixels = batch * DOM_H * DOM_W
-    flops = 2.0 * pixels * (3 * DOM_C) * DOM_C
-    nbytes = 2 * pixels * DOM_C * 4
-    achieved = flops / (ms * 1e-3) / 1e12
-    peak = BF16_MATRIX_PEAK_TFLOPS / 6.0
+    ms = event_time_ms(lambda: hipf.conv_line_split(x, packed, b, 0, dil, True), device, 50)
+    pixels = batch * h * w_
+    flops = 2.0 * pixels * (3 * c) * c
+    nbytes = 2 * pixels * c * 4
+    t = ms * 1e-3
+    mfma_peak = BF16_MATRIX_PEAK_TFLOPS / 6.0
+    mfma_floor_us = flops / (mfma_peak * 1e12) * 1e6
+    hbm_floor_us = nbytes / (HBM_PEAK_GBS * 1e9) * 1e6
+    name = f"line_x3r_kernel<{c}, 64>"
+    return {"kernel": f"{name} (conv3x1 dilation {dil} + bias + ReLU, {c}->{c} channels, {batch}x{h}x{w_} pixels, "
+                      "fp32 tensors, split-bf16 arithmetic)",
+            "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops, "algorithmic_bytes_per_launch": nbytes,
+            "tflops": round(flops / t / 1e12, 2), "mfma_peak_tflops": round(mfma_peak, 1),
+            "mfma_frac": round(flops / t / 1e12 / mfma_peak, 4), "mfma_floor_us": round(mfma_floor_us, 2),
+            "executed_bf16_tflops": round(6 * flops / t / 1e12, 1),
+            "hbm_gbs": round(nbytes / t / 1e9, 1), "hbm_frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+            "hbm_floor_us": round(hbm_floor_us, 2),
+            "share_of_step": step_share(name)}
+
+
+def dominant_kernel_roofline(device, batch):
+    """The fp32 training step spends half of its time in the two widths of line_x3r_kernel (every 1-D
+    convolution of the 64- and 128-channel non_bottleneck_1d blocks, forward and data gradient).  Both
+    are timed live with HIP events on the stream they run on; `roofline` is the width with the larger
+    share of the step in the committed profile (profiles/r3_train_f32_kernel_stats.csv), the other one
+    is reported beside it.  The bound is whichever floor is higher for that launch: the bf16 matrix
+    pipe at six MFMA terms per fp32 product (dense bf16 peak / 6), or HBM at input + output once."""
+    k64 = line_conv_roofline(device, batch, 64, 4, 1)
+    k128 = line_conv_roofline(device, batch, 128, 8, 2)
+    s64, s128 = k64["share_of_step"] or 0.0, k128["share_of_step"] or 0.0
+    dom, other = (k64, k128) if s64 >= s128 else (k128, k64)
     traffic, source = None, None
     tj = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
     if os.path.exists(tj):
         try:
             rec = json.load(open(tj))
-            if rec.get("kernel", "").startswith("line_x3_kernel"):
+            if rec.get("kernel", "").replace(" ", "") == dom["kernel"].split(" (")[0].replace(" ", ""):
                 traffic = rec.get("hbm_bytes_per_launch")
                 source = "profiles/dominant_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
                          "not measured in this run)"
         except Exception:
             traffic = None
-    out = {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
-           "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-           "traffic_source": source,
-           "kernel": "line_x3_kernel<128,64> (conv3x1 dilation 2 + ReLU, 128->128 channels, fp32 tensors, "
-                     "split-bf16 arithmetic)",
-           "peak_note": "dense bf16 MFMA peak / 6: each fp32 product costs six bf16 MFMA terms; achieved counts "
-                        "the convolution's algorithmic FLOPs once",
-           "executed_bf16_tflops": round(6 * achieved, 1),
-           "frac_of_fp32_matrix_peak": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4),
-           "us_per_launch": round(ms * 1e3, 2), "flops_per_launch": flops,
-           "algorithmic_bytes_per_launch": nbytes,
-           "hbm_gbs": round(nbytes / (ms * 1e-3) / 1e9, 1),
-           "hbm_frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-           "hbm_bound_us": round(nbytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2)}
-    # the fp32-MFMA kernel it replaced (ERF_OPT_SPLIT_BF16 = 0): two chained convolutions per launch
-    wa = (torch.randn(DOM_C, DOM_C, 1, 3, generator=g) * 0.05).to(device)
-    pk2 = hipf.conv_pair_pack(wa, w)
-    ms2 = event_time_ms(lambda: hipf.conv_pair(x, pk2, b, b, 1, 2, 2, keep_mid=True), device, 30)
-    out["fp32_mfma_pair_kernel"] = {"kernel": "pair_f32_kernel<64,128> (conv1x3 + conv3x1 in one launch)",
-                                    "us_per_launch": round(ms2 * 1e3, 2),
-                                    "tflops": round(2 * flops / (ms2 * 1e-3) / 1e12, 2),
-                                    "frac_of_fp32_matrix_peak": round(2 * flops / (ms2 * 1e-3) / 1e12 /
-                                                                      FP32_MATRIX_PEAK_TFLOPS, 4)}
+    hbm_bound = dom["hbm_floor_us"] >= dom["mfma_floor_us"]
+    out = {"bound": "hbm" if hbm_bound else "mfma",
+           "achieved": dom["hbm_gbs"] if hbm_bound else dom["tflops"],
+           "peak": HBM_PEAK_GBS if hbm_bound else dom["mfma_peak_tflops"],
+           "unit": "GB/s" if hbm_bound else "TFLOP/s",
+           "frac": dom["hbm_frac"] if hbm_bound else dom["mfma_frac"],
+           "traffic": traffic, "traffic_source": source,
+           "peak_note": "mfma: dense bf16 MFMA peak / 6 (each fp32 product costs six bf16 MFMA terms; the "
+                        "convolution's algorithmic FLOPs are counted once); hbm: 8 TB/s against input read + "
+                        "output written once",
+           "frac_of_fp32_matrix_peak": round(dom["tflops"] / FP32_MATRIX_PEAK_TFLOPS, 4)}
+    out.update(dom)
+    out["other_width"] = other
     return out
 
 

@@ -35,6 +35,12 @@ __device__ __forceinline__ unsigned x3r_opaque(unsigned v)
     return v;
 }
 
+#ifndef X3R_PFA64
+#define X3R_PFA64 1
+#endif
+#ifndef X3R_PFA128
+#define X3R_PFA128 2
+#endif
 template <int NC, int BM>
 __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const LineDesc d)
 {
@@ -309,9 +315,26 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
         const int px = (wp * WM + a) * 32 + l31;
         vb[a] = (unsigned)(px * d.pstride * NC + 32 * cg + 4 * h) * 4u;
     }
+    // The residual (or, without one, the mask) of an output line is requested when the line's steps
+    // begin and has landed when the epilogue needs it; with both tensors the mask is read in the
+    // epilogue.  PFA pixel tiles of a wave are covered (register budget).
+    constexpr int PFA0 = NC == 64 ? X3R_PFA64 : X3R_PFA128, PFA = PFA0 < WM ? PFA0 : WM;
+    const bool has_res = d.epi1.res != nullptr, masked = d.epi1.mask != nullptr;        // wave-uniform
+    const __amdgpu_buffer_rsrc_t rpf = make_rsrc(has_res ? d.epi1.res : d.epi1.mask, tbytes);
+    f32x4 pf[PFA > 0 ? PFA : 1][4];
+    auto prefetch = [&](unsigned soff, int len) __attribute__((always_inline)) {
+        if (PFA == 0 || (!has_res && !masked)) return;
+#pragma unroll
+        for (int a = 0; a < PFA; ++a) {
+            const int px = (wp * WM + a) * 32 + (int)x3r_opaque((unsigned)l31);
+            const unsigned vo = px < len ? x3r_opaque(vb[a]) : ERF_OOB;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                pf[a][gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rpf, (int)vo, (int)(soff + 32u * gq), 0));
+        }
+    };
     auto finish_t = [&](auto relu_t, auto scale_t, auto res_t, unsigned soff, int len) __attribute__((always_inline)) {
         constexpr bool RELU = decltype(relu_t)::value, SCALE = decltype(scale_t)::value, RES = decltype(res_t)::value;
-        const bool masked = d.epi1.mask != nullptr;         // wave-uniform
 #pragma unroll
         for (int a = 0; a < WM; ++a) {
             const int px = (wp * WM + a) * 32 + (int)x3r_opaque((unsigned)l31);
@@ -320,7 +343,8 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
             if (RES) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
-                    rr[gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)vo, (int)(soff + 32u * gq), 0));
+                    rr[gq] = a < PFA ? pf[a < PFA ? a : 0][gq]
+                                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)vo, (int)(soff + 32u * gq), 0));
             }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
@@ -338,7 +362,8 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
                 f32x4 mm[4];
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
-                    mm[gq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)vo, (int)(soff + 32u * gq), 0));
+                    mm[gq] = (!RES && a < PFA) ? pf[a < PFA ? a : 0][gq]
+                                               : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rmk, (int)vo, (int)(soff + 32u * gq), 0));
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
@@ -375,6 +400,7 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
     auto output_line = [&](auto first_c, bool more) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value;
         const bool lo_valid = j > 0, hi_valid = j + 1 < Lc;
+        prefetch(ok.base + (unsigned)j * lstep, ok.len);
         if (FIRST) {
             // the first centre step fetches the other taps' weights; it hosts the split of line j-1, or
             // (no line below) of the line the steps after it need
