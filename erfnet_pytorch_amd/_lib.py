@@ -137,6 +137,7 @@ BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
 OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16, OPT_PAIR16, OPT_LINE2, OPT_SPLIT_BF16, OPT_CONV16_ROWS, OPT_X3_ROLL = 1, 2, 3, 4, 5, 6, 7, 8
 
 EXPORTS = tuple(_PROTOS)
+ABI_VERSION = 102                         # ERF_ABI_VERSION of include/erfnet_hip.h
 
 
 def lib():
@@ -163,6 +164,11 @@ def lib():
         except (OSError, AttributeError) as e:
             _load_error = f"cannot load {_SO}: {e}"
             raise RuntimeError(_load_error) from e
+        have = int(handle.erf_version())
+        if have != ABI_VERSION:
+            _load_error = (f"{_SO} has ABI revision {have}, this package expects {ABI_VERSION}: rebuild it "
+                           f"(python -c 'import __graft_entry__ as g; g.build()')")
+            raise RuntimeError(_load_error)
         _lib = handle
     return _lib
 

@@ -1533,6 +1533,13 @@ int static_scratch(void **out)
     *out = g_scratch_ptr[dev];
     return 0;
 }
+bool static_scratch_resolved()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return g_scratch_ptr[dev] != nullptr;
+}
 }  // namespace
 
 namespace {
@@ -1579,7 +1586,10 @@ int opt_launch(const char *what, int count, float *const *p, const float *const 
 
 extern "C" {
 
-int erf_version(void) { return 100; }
+int erf_version(void)
+{
+    return ERF_ABI_VERSION;
+}
 
 int erf_set_option(int option, int value)
 {
@@ -2473,6 +2483,15 @@ static int cross_entropy_forward_impl(const float *logits, const long long *targ
 {
     hipStream_t st = (hipStream_t)stream;
     Arena ar(ws, ws_bytes);
+    {   // look the static scratch array's address up on this device while no capture can be under way
+        // through this entry point's caller-provided workspace (erf_cross_entropy_forward_static then
+        // never has to do it inside a capture); failure here is not an error of this call
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (!static_scratch_resolved() && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {
+            void *unused = nullptr;
+            if (static_scratch(&unused)) g_err[0] = 0;
+        }
+    }
     if (K < 1) return fail("cross entropy: no classes");
     const long long P = (long long)N * H * W;
     if (P == 0) return fail("cross entropy: empty input");
@@ -2528,6 +2547,14 @@ int erf_cross_entropy_forward_static(const float *logits, const long long *targe
                     max_blocks * CE_BLOCK);
     if (!logits || !target || !stats || !lse) return fail("cross entropy: null pointer");
     void *sp = nullptr;
+    if (!static_scratch_resolved()) {
+        // the first call on a device looks the array's address up; that is not a stream operation and
+        // must not fall inside a capture (every erf_cross_entropy_forward* call does the look-up too)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail("cross entropy (static scratch): the first call on a device must be made outside stream "
+                        "capture (it resolves the scratch array's address)");
+    }
     if (static_scratch(&sp)) return 1;
     // every block overwrites its own pair of partial sums before the reduction reads them, so
     // nothing of an earlier call's contents has to be cleared

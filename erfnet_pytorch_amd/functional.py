@@ -78,8 +78,16 @@ def _fn(name, x):
 
 
 # Parameters are handed to the library in fp32 (the kernels repack / round them per call).  A model
-# converted with .bfloat16() is served through fp32 copies, refreshed when a parameter changes.
+# converted with .bfloat16() is served through fp32 copies, refreshed when a parameter's version
+# counter moves (optimiser steps, copy_, load_state_dict) or its storage is replaced (the reference's
+# `target.data = ...`, train/main.py:142).  An in-place update through a `.data` alias
+# (`p.data.mul_(a)`) moves neither: code that does that calls invalidate_parameter_copies().
 _fp32_copies = {}
+
+
+def invalidate_parameter_copies():
+    """Drop the fp32 copies kept of non-fp32 parameters (see above); the next call converts afresh."""
+    _fp32_copies.clear()
 
 
 def _as_fp32(t):
@@ -675,9 +683,11 @@ def upsampler(x, w, b, bn_weight=None, bn_bias=None, running_mean=None, running_
 # and runs one fused kernel (erf_outconv_ce_backward).  Because the stand-in is zero, gradients that
 # other consumers of the logits add to it (the mean-teacher consistency loss, train/main.py:353)
 # stay correct: the convolution then sees a tensor that is not the stand-in, materialises the
-# deposited loss gradients and takes the ordinary path.  What does NOT see the loss gradient is
+# deposited loss gradients and takes the ordinary path.  What cannot see the loss gradient is
 # code that asks autograd for the gradient of the logits themselves (torch.autograd.grad(loss,
-# logits), logits.retain_grad() after the loss was built): call set_loss_handover(False) for that.
+# logits), logits.retain_grad() after the loss was built): such a pass ends with the deposit still
+# in the token, which raises (and withdraws the deposit, so that a later pass is not doubled);
+# call set_loss_handover(False) for that use.
 _LOSS_HANDOVER = True
 
 
@@ -906,7 +916,23 @@ class _CrossEntropy(torch.autograd.Function):
         gy = gy.to(torch.float32).reshape(1).contiguous()
         tok = ctx.loss_token
         if tok is not None and _LOSS_HANDOVER:
-            tok.pending.append((tg, lse, stats, gy, ctx.ignore_index, x))
+            entry = (tg, lse, stats, gy, ctx.ignore_index, x)
+            tok.pending.append(entry)
+
+            def settle():
+                # End of this backward pass.  A deposit nobody collected means the output convolution's
+                # backward did not run in it — the caller asked autograd for the gradient of the logits
+                # themselves and was handed the zero stand-in.  Left in place, the deposit would also be
+                # added to the next pass's gradient.  Withdraw it and fail loudly.
+                for i, e in enumerate(tok.pending):
+                    if e is entry:
+                        del tok.pending[i]
+                        raise RuntimeError(
+                            "erfnet_pytorch_amd: the gradient of the logits was requested from autograd while the "
+                            "loss hand-over is on (CrossEntropyLoss2d hands its gradient straight to the output "
+                            "convolution's backward); call functional.set_loss_handover(False) before building "
+                            "the graph to get d(loss)/d(logits) itself")
+            torch.autograd.Variable._execution_engine.queue_callback(settle)
             return tok.zero.expand(x.shape), None, None
         return _cross_entropy_grad(x, tg, lse, stats, gy, ctx.ignore_index), None, None
 

@@ -46,6 +46,13 @@ def copyWeightsToModelWithDiscount(model_source, model_target, discount_factor):
             _lib.check(_lib.lib().erf_ema_update(n, tp, sp, ne, float(discount_factor),
                                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         return
+    # Any other storage type or device: torch's multi-tensor operations on the parameters themselves
+    # (not on their .data aliases, whose in-place updates leave the parameters' version counters
+    # untouched — the fp32 copies that functional.py keeps of non-fp32 parameters are refreshed by
+    # that counter), and the copies are dropped explicitly as well.
+    params = list(model_target.parameters())
     with torch.no_grad():
-        torch._foreach_mul_(targets, 1.0 - discount_factor)
-        torch._foreach_add_(targets, sources, alpha=discount_factor)
+        torch._foreach_mul_(params, 1.0 - discount_factor)
+        torch._foreach_add_(params, sources, alpha=discount_factor)
+    from . import functional
+    functional.invalidate_parameter_copies()

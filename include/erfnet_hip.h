@@ -45,7 +45,12 @@ typedef struct {
     long long *num_batches_tracked;
 } erf_bn_t;
 
-/* Library identification / diagnostics. */
+/* Library identification / diagnostics.  erf_version() returns the ABI revision the library was
+ * built with; a caller compiled against this header compares it with ERF_ABI_VERSION and refuses a
+ * mismatch (struct layouts are part of the ABI: revision 101 added erf_bn_t::num_batches_tracked and
+ * changed erf_nb1d_block_t's member types, 102 added ERF_OPT_X3_ROLL and the capture rule of
+ * erf_cross_entropy_forward_static). */
+#define ERF_ABI_VERSION 102
 int erf_version(void);
 const char *erf_last_error(void);
 /* Number of kernel launches issued through this library by the calling process (tests use it to
@@ -246,7 +251,10 @@ int erf_cross_entropy_forward_counts(const float *logits, const long long *targe
  * reference.  The block partial sums go to a 1 MiB array inside the library's code object (one
  * copy per GPU, held until the process ends), so the call allocates nothing and takes no `ws`;
  * results equal erf_cross_entropy_forward bit for bit.  At most 33,554,432 pixels (N*H*W) per
- * call; larger inputs are rejected.  The device whose stream is passed must be current.  All calls
+ * call; larger inputs are rejected.  The device whose stream is passed must be current.  The first
+ * call on a device resolves the array's address and is rejected while that stream is being captured
+ * (any earlier erf_cross_entropy_forward / _counts call on the device resolves it as well); later
+ * calls may be captured.  All calls
  * on one GPU share that array: calls that overlap in time on the same GPU (two streams) race;
  * calls on one stream are ordered and need no clearing in between. */
 #define ERF_CE_STATIC_MAX_PIXELS 33554432LL

@@ -224,3 +224,71 @@ def test_flat_parameters_give_the_same_adam_steps():
     assert a.keys() == b.keys()
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_direct_written_gradients_still_launch_buckets_from_inside_backward():
+    """With direct_write the kernels write a weight gradient into its bucket slice and hand autograd
+    None; the reducer counts that parameter in the post-accumulate hook autograd still runs for it.
+    If a torch version stopped running the hook for an undefined gradient, every bucket would leave
+    from finish() only — correct, but without any overlap with backward, and unnoticed.  Here: a
+    layer that delivers its gradients exactly the way the HIP blocks do (functional._grad_targets /
+    _deliver), a one-rank gloo group with reduce_single_rank, and the assertion that the buckets'
+    all-reduces were launched before finish()."""
+    sys.path.insert(0, ROOT)
+    from erfnet_pytorch_amd import functional as hipf
+    from erfnet_pytorch_amd.ddp import GradientReducer
+
+    class DirectLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.save_for_backward(x, w)
+            ctx.params = (w, b)
+            return x @ w.t() + b
+
+        @staticmethod
+        def backward(ctx, gy):
+            x, w = ctx.saved_tensors
+            tg = hipf._grad_targets(ctx.params, (w.shape, (w.shape[0],)), x.device)
+            tg[0][0].copy_(gy.t() @ x)              # what a kernel does: write into the buffer it was given
+            tg[1][0].copy_(gy.sum(0))
+            dw, db = hipf._deliver(tg)
+            return gy @ w, dw, db
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([torch.nn.Linear(32, 32) for _ in range(6)])
+
+        def forward(self, x):
+            for l in self.layers:
+                x = torch.relu(DirectLinear.apply(x, l.weight, l.bias))
+            return x
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        torch.manual_seed(3)
+        model = Net()
+        ref = Net()
+        ref.load_state_dict(model.state_dict())
+        red = GradientReducer(model, bucket_bytes=2 * (32 * 32 + 32) * 4, direct_write=True, reduce_single_rank=True)
+        x = torch.rand(8, 32)
+        for step in range(3):
+            red.zero_grad()
+            model(x).sum().backward()
+            if step > 0:
+                # every bucket complete -> launched from the hook, i.e. before finish()
+                assert all(v == -1 for v in red._pending.values()), (step, red._pending)
+                assert len(red._written) == 12              # all weights and biases took the direct path
+            red.finish()
+        for p in ref.parameters():
+            p.grad = None
+        y = x
+        for l in ref.layers:
+            y = torch.relu(l(y))
+        y.sum().backward()
+        for (k, p), q in zip(model.named_parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, atol=1e-5), k
+    finally:
+        dist.destroy_process_group()

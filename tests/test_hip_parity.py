@@ -598,6 +598,42 @@ def test_loss_hand_over_matches_separate_kernels(mode, dtype, ncls):
         gu.check_arrays(u, v, 1e-7, 1e-5, what=f"{mode}/{nm}", scale_rtol=tol)
 
 
+def test_gradient_of_the_logits_themselves_is_refused_loudly_under_hand_over():
+    """torch.autograd.grad(loss, logits) cannot be served by the hand-over (the loss gradient goes
+    straight to the output convolution): the pass must raise instead of returning the zero stand-in,
+    and must leave nothing behind — a following ordinary backward gives the ordinary gradients.  With
+    the hand-over off the gradient of the logits is the real one."""
+    from erfnet_pytorch_amd import functional as hipf
+    from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
+    shape, ncls = (2, 16, 12, 20), 20
+    x = t(np.maximum(gu.det_normal("losshead.x", shape), 0)).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    wt = t(0.3 * gu.det_normal("losshead.w", (16, ncls, 2, 2))).requires_grad_(True)
+    b = t(0.1 * gu.det_normal("losshead.b", (ncls,))).requires_grad_(True)
+    lab = t(gu.det_labels("losshead.lab", (2, 24, 40), -1, ncls))
+    y = hipf.outconv(x, wt, b)
+    loss = CrossEntropyLoss2d()(y, lab)
+    with pytest.raises(RuntimeError, match="set_loss_handover"):
+        torch.autograd.grad(loss, y, retain_graph=True)
+    loss.backward()
+    got = [v.grad.clone() for v in (x, wt, b)]
+    for v in (x, wt, b):
+        v.grad = None
+    old = hipf.set_loss_handover(False)
+    try:
+        y2 = hipf.outconv(x, wt, b)
+        loss2 = CrossEntropyLoss2d()(y2, lab)
+        (gl,) = torch.autograd.grad(loss2, y2, retain_graph=True)
+        assert float(gl.abs().max()) > 0
+        ref = torch.nn.functional.cross_entropy(y2.detach().clone().requires_grad_(True), lab, ignore_index=-1)
+        loss2.backward()
+    finally:
+        hipf.set_loss_handover(old)
+    assert abs(float(ref) - float(loss2)) < 1e-5
+    for nm, u, v in zip(("dx", "dw", "db"), got, (x, wt, b)):
+        gu.check_arrays(u.cpu().numpy(), v.grad.cpu().numpy(), 1e-7, 1e-5, what=nm, scale_rtol=2e-5)
+
+
 def test_graphed_forward_replays_the_eager_result():
     """A forward captured into a HIP graph (graphs.GraphedForward) returns bit-identical logits on
     replay, for the captured input and for new data of the same shape."""

@@ -309,3 +309,25 @@ def test_training_step_with_library_adam_matches_reference():
     mean_teacher.copyWeightsToModelWithDiscount(net, teacher, 0.01)
     for b, s, tp in zip(before, net.parameters(), teacher.parameters()):
         assert torch.equal(tp.detach(), b * (1 - 0.01) + 0.01 * s.detach())       # train/main.py:142
+
+
+@pytest.mark.gpu
+def test_mean_teacher_update_reaches_a_bf16_teacher():
+    """A teacher kept in bf16 (model.bfloat16()) is served through fp32 copies of its parameters; the
+    mean-teacher update (train/main.py:140-142,390) must be visible to the very next forward — the
+    copies are refreshed, not reused."""
+    from erfnet_pytorch_amd import mean_teacher
+    from test_hip_parity import make_model
+    student = gu.fill_state_dict(make_model("net_classification_20"), tag="mt.student").to(DEV).eval()
+    teacher = gu.fill_state_dict(make_model("net_classification_20"), tag="mt.teacher").to(DEV).eval().bfloat16()
+    x = torch.from_numpy(gu.det_uniform("mt.x", (1, 3, 64, 128), 0.0, 1.0)).to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        y0 = teacher(x)[0].float().clone()
+        mean_teacher.copyWeightsToModelWithDiscount(student, teacher, 0.5)
+        y1 = teacher(x)[0].float().clone()
+        # the same weights in a fresh model: nothing cached can be involved
+        fresh = make_model("net_classification_20").to(DEV).eval().bfloat16()
+        fresh.load_state_dict(teacher.state_dict())
+        y2 = fresh(x)[0].float()
+    assert float((y1 - y0).abs().max()) > 1e-3 * float(y0.abs().max()), "the update did not reach the forward pass"
+    assert torch.equal(y1, y2)

@@ -65,3 +65,41 @@ def test_static_scratch_cross_entropy_matches_workspace_entry_point():
     assert rc != 0
     assert b"exceed the limit" in lib.erf_last_error()
     assert _lib.launch_count() == n_launch
+
+
+@pytest.mark.timeout(120)
+def test_static_scratch_cross_entropy_replays_from_a_hip_graph():
+    """The callers the entry point exists for: after one ordinary call on the device (which resolves
+    the scratch array's address), the call is captured into a HIP graph and replayed on new data —
+    nothing in it allocates, and the replayed results equal the workspace entry point's."""
+    from erfnet_pytorch_amd import _lib
+    lib = _lib.lib()
+    n, k, h, w = 2, 20, 48, 64
+    logits = torch.as_tensor(gu.det_normal("noalloc.g.logits", (n, k, h, w))).to(DEV) * 2.0
+    target = torch.as_tensor(gu.det_labels("noalloc.g.lab", (n, h, w), -1, k)).to(DEV)
+    stats = torch.zeros(2, device=DEV)
+    lse = torch.zeros((n, h, w), device=DEV)
+
+    def call(stream):
+        return lib.erf_cross_entropy_forward_static(_ptr(logits), _ptr(target), _ptr(stats), _ptr(lse), n, k, h, w, -1,
+                                                    C.c_void_p(stream.cuda_stream))
+    _lib.check(call(torch.cuda.current_stream()))          # warm-up outside capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.graph(graph, stream=side):
+        rc = call(torch.cuda.current_stream())
+    _lib.check(rc)
+    for seed in (1, 2):
+        logits.copy_(torch.as_tensor(gu.det_normal(f"noalloc.g.logits{seed}", (n, k, h, w))).to(DEV) * 2.0)
+        stats.fill_(-1.0)
+        lse.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        ws = torch.empty(int(lib.erf_workspace_bytes(n * h * w, k)), dtype=torch.uint8, device=DEV)
+        s2, l2 = torch.zeros(2, device=DEV), torch.zeros((n, h, w), device=DEV)
+        _lib.check(lib.erf_cross_entropy_forward(_ptr(logits), _ptr(target), _ptr(s2), _ptr(l2), n, k, h, w, -1,
+                                                 _ptr(ws), ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        assert torch.equal(stats, s2) and torch.equal(lse, l2), seed
