@@ -117,3 +117,47 @@ def test_batch_statistics_from_the_convolution_kernel(split_on):
     # (running_var is an fp32 number near 0.9 + 0.1 var: recovering var from it costs ~1e-6 absolute)
     assert ((got_var - var_unb).abs() - 2e-5 * var_unb).max().item() <= 3e-6
     assert int(blk.bn1.num_batches_tracked) == 1
+
+
+def test_split_kernels_on_non_finite_and_tiny_inputs():
+    """Documented edge behaviour of the split arithmetic (x = hi + mid + lo in bf16):
+      * a non-finite input element makes every output that reads it NaN (inf - inf in the split),
+        where an fp32 convolution would give +-inf or NaN; finite neighbours are unaffected;
+      * magnitudes down to 2^-100 keep all three terms (the low term is 2^-16 of the value, far above
+        the smallest bf16 normal 2^-126): relative error stays at the fp32 level;
+      * below about 2^-110 the low terms underflow in bf16 and the result degrades towards the
+        precision of the surviving terms — it must still be within 2^-8 relative (the high term alone)
+        and exactly zero inputs give exactly zero."""
+    from erfnet_pytorch_amd import functional as hipf
+    C_, N, H, W, dil = 64, 1, 24, 70, 1
+    g = torch.Generator().manual_seed(123)
+    w = torch.randn(C_, C_, 3, 1, generator=g) * 0.05
+    b = torch.zeros(C_)
+    packed = hipf.conv_line_pack_split(w.to(DEV))
+    x = torch.randn(N, C_, H, W, generator=g)
+
+    def run(xx):
+        return hipf.conv_line_split(xx.to(DEV), packed, b.to(DEV), 0, dil, False).cpu()
+
+    def ref64(xx):
+        return F.conv2d(xx.double(), w.double(), None, padding=(dil, 0), dilation=(dil, 1))
+
+    # non-finite
+    for bad in (float("inf"), float("-inf"), float("nan")):
+        xb = x.clone()
+        xb[0, 5, 10, 33] = bad
+        y = run(xb)
+        hit = torch.zeros(N, 1, H, W, dtype=torch.bool)
+        hit[0, 0, 9:12, 33] = True                       # the three output rows whose taps read row 10
+        assert torch.isnan(y[hit.expand_as(y)]).all(), bad
+        clean = ~hit.expand_as(y)
+        r = ref64(x)
+        assert torch.isfinite(y[clean]).all()
+        assert (y.double() - r)[clean].abs().max() <= 4e-6 * r.abs().max()
+    # tiny magnitudes: full accuracy at 2^-100
+    for e, tol in ((-100, 4e-6), (-120, 2.0 ** -8)):
+        xs = x * 2.0 ** e
+        y, r = run(xs), ref64(xs)
+        assert torch.isfinite(y).all()
+        assert (y.double() - r).abs().max() <= tol * r.abs().max(), e
+    assert torch.equal(run(torch.zeros_like(x)), torch.zeros(N, C_, H, W))
