@@ -2402,6 +2402,38 @@ static int outconv_ce_backward_impl(int dt, const void *x, const float *w, const
     return 0;
 }
 
+// Output convolution + CrossEntropyLoss forward in one kernel (outconv_ce_fwd_kernel): loss, labelled
+// pixel count, per-pixel log-sum-exp and (optionally) the accuracy counts, the logits never stored.
+static int outconv_ce_forward_impl(int dt, const void *x, const float *w, const float *b, const long long *target,
+                                   float *stats, float *lse, long long *counts, int N, int Cin, int H, int W, int ncls,
+                                   long long ignore_index, void *ws, size_t ws_bytes, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    Arena ar(ws, ws_bytes);
+    if (Cin != OC_CIN) return fail("output ConvTranspose2d: Cin must be %d (got %d)", OC_CIN, Cin);
+    if (ncls < 1 || ncls > OC_MAX_NCLS) return fail("output ConvTranspose2d: 1 <= classes <= %d", OC_MAX_NCLS);
+    if (!x || !w || !target || !stats || !lse) return fail("output ConvTranspose2d + loss forward: null pointer");
+    if (!aligned16(x) || !aligned16(target) || ((uintptr_t)lse & 7))
+        return fail("output ConvTranspose2d + loss forward: misaligned tensors");
+    const long long M = (long long)N * H * W;
+    if (M == 0) return fail("output ConvTranspose2d + loss forward: empty input");
+    if (M * OC_CIN >= (1LL << 29)) return fail("output ConvTranspose2d + loss forward: tensors of 2 GiB or more are not supported");
+    const long long blocks = (M + 255) / 256;
+    float *partial = ar.floats((size_t)blocks * 2);
+    unsigned *cpartial = counts ? (unsigned *)ar.take((size_t)blocks * 2 * ncls * sizeof(unsigned)) : nullptr;
+    if (!partial || (counts && !cpartial)) return fail("output ConvTranspose2d + loss forward: workspace too small");
+    OutConvCeFwdDesc d = {x, w, b, target, lse, partial, cpartial, N, H, W, ncls, ignore_index};
+    BY_DT(dt, (outconv_ce_fwd_kernel<T><<<(unsigned)blocks, 256, 0, st>>>(d)));
+    CHECK_LAUNCH("outconv_ce_fwd_kernel");
+    ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
+    CHECK_LAUNCH("ce_reduce_kernel");
+    if (counts) {
+        ce_count_sum_kernel<<<2 * ncls, 256, 0, st>>>(cpartial, (int)blocks, 2 * ncls, counts);
+        CHECK_LAUNCH("ce_count_sum_kernel");
+    }
+    return 0;
+}
+
 // ================================================================================ plain Conv2d
 static void conv2d_taps(int k, int *dh, int *dw, int *woff, bool transpose)
 {
@@ -2920,6 +2952,20 @@ int erf_outconv_ce_backward_bf16(const void *x, const float *w, const float *b, 
 {
     return outconv_ce_backward_impl(ERF_DT_BF16, x, w, b, target, lse, stats, gy, dx, dw, db, N, Cin, H, W, ncls,
                                     ignore_index, flags, ws, ws_bytes, stream);
+}
+int erf_outconv_ce_forward(const float *x, const float *w, const float *b, const long long *target, float *stats,
+                           float *lse, long long *counts, int N, int Cin, int H, int W, int ncls,
+                           long long ignore_index, void *ws, size_t ws_bytes, void *stream)
+{
+    return outconv_ce_forward_impl(ERF_DT_F32, x, w, b, target, stats, lse, counts, N, Cin, H, W, ncls, ignore_index,
+                                   ws, ws_bytes, stream);
+}
+int erf_outconv_ce_forward_bf16(const void *x, const float *w, const float *b, const long long *target, float *stats,
+                                float *lse, long long *counts, int N, int Cin, int H, int W, int ncls,
+                                long long ignore_index, void *ws, size_t ws_bytes, void *stream)
+{
+    return outconv_ce_forward_impl(ERF_DT_BF16, x, w, b, target, stats, lse, counts, N, Cin, H, W, ncls, ignore_index,
+                                   ws, ws_bytes, stream);
 }
 int erf_outconv_argmax(const float *x, const float *w, const float *b, long long *labels, int N, int Cin,
                        int H, int W, int ncls, void *stream)

@@ -9,6 +9,7 @@
 // the mean's denominator); torch's kernel stops the process with a device-side assert on such a label.
 #pragma once
 #include "common.h"
+#include "aux_kernels.h"
 
 #define CE_BLOCK 256
 #define CE_MAX_K 32
@@ -144,6 +145,132 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float *partial, in
         stats[0] = (float)(red[0][0] / red[1][0]);     // 0/0 = NaN when nothing is labelled, as in torch
         stats[1] = (float)red[1][0];
     }
+}
+
+// Output convolution + CrossEntropyLoss in one pass, for the training loop whose only use of the logits
+// is `criterion(outputs, targets)` (train/main.py:327,343-347): the logits of
+// ConvTranspose2d(16, K, 2, stride=2) (train/net_classification.py:56,64) are formed in registers —
+// the same fused-multiply-add chain as outconv_fwd_kernel, so the log-sum-exp kept for backward equals
+// the two-kernel path's bit for bit — and never reach memory: 64 B of x and 32 B of labels read, 16 B
+// of log-sum-exp written per input pixel instead of 4*K*4 B of logits written and read again.
+// One thread per INPUT pixel (four output positions); block sums in a fixed order.
+struct OutConvCeFwdDesc {
+    const void *x;              // NHWC [N][H][W][16], storage type T
+    const float *w, *b;         // [16][K][2][2], [K]
+    const long long *target;    // [N][2H][2W]
+    float *lse;                 // [N][2H][2W]
+    float *partial;             // [blocks][2]
+    unsigned *cpartial;         // optional: [blocks][2][K]
+    int N, H, W, K;
+    long long ignore_index;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void outconv_ce_fwd_kernel(const OutConvCeFwdDesc d)
+{
+    __shared__ __attribute__((aligned(16))) float ws[OC_MAX_NCLS * 4 * OC_CIN];
+    __shared__ float bs[OC_MAX_NCLS];
+    __shared__ float red[2][4];
+    __shared__ unsigned hist[2 * CE_MAX_K];
+    const int K = d.K;
+    for (int i = threadIdx.x; i < K * 4 * OC_CIN; i += 256) {
+        const int c = i % OC_CIN, ab = (i / OC_CIN) % 4, o = i / (OC_CIN * 4);
+        ws[i] = d.w[(c * K + o) * 4 + ab];
+    }
+    for (int i = threadIdx.x; i < K; i += 256) bs[i] = d.b ? d.b[i] : 0.0f;
+    const bool counting = d.cpartial != nullptr;
+    if (threadIdx.x < 2 * CE_MAX_K) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const long long M = (long long)d.N * d.H * d.W;
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    float loss = 0.0f, cnt = 0.0f;
+    if (m < M) {
+        const int n = (int)(m / (d.H * d.W));
+        const int rem = (int)(m - (long long)n * d.H * d.W);
+        const int i = rem / d.W, j = rem - i * d.W;
+        float xv[OC_CIN];
+#pragma unroll
+        for (int q = 0; q < OC_CIN / 4; ++q) {
+            const f32x4 v = Act<T>::ld4(d.x, m * OC_CIN + q * 4);
+            xv[q * 4] = v[0]; xv[q * 4 + 1] = v[1]; xv[q * 4 + 2] = v[2]; xv[q * 4 + 3] = v[3];
+        }
+        const int Wo = 2 * d.W;
+        const long long o0 = ((long long)n * 2 * d.H + 2 * i) * Wo + 2 * j;     // output position (a = 0, b = 0)
+        long long tg[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            // (two consecutive int64 labels: one 16-byte load; the row offset is even, so it is aligned)
+            const longlong2 t2 = *reinterpret_cast<const longlong2 *>(d.target + o0 + (long long)a * Wo);
+            tg[a * 2] = t2.x; tg[a * 2 + 1] = t2.y;
+        }
+        // first pass over the classes: the maxima and the arg-max; the labelled class's logit on the way
+        float mx[4], best[4], tl[4];
+        int arg[4];
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) { mx[ab] = -INFINITY; best[ab] = 0.0f; arg[ab] = 0; tl[ab] = 0.0f; }
+        for (int o = 0; o < K; ++o)
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                float r = bs[o];
+                const float *w0 = &ws[(o * 4 + ab) * OC_CIN];
+#pragma unroll
+                for (int c = 0; c < OC_CIN; ++c) r = fmaf(xv[c], w0[c], r);
+                mx[ab] = o == 0 ? r : fmaxf(mx[ab], r);
+                // first largest value, NaN wins: torch's argmax
+                const bool take = o == 0 || r > best[ab] || (r != r && best[ab] == best[ab]);
+                best[ab] = take ? r : best[ab];
+                arg[ab] = take ? o : arg[ab];
+                tl[ab] = (long long)o == tg[ab] ? r : tl[ab];
+            }
+        // second pass: the sum of exponentials in class order (the order of ce_fwd_kernel)
+        float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int o = 0; o < K; ++o)
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                float r = bs[o];
+                const float *w0 = &ws[(o * 4 + ab) * OC_CIN];
+#pragma unroll
+                for (int c = 0; c < OC_CIN; ++c) r = fmaf(xv[c], w0[c], r);
+                sum[ab] += __expf(r - mx[ab]);
+            }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f32x2 l2;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int ab = a * 2 + b;
+                const float lse = mx[ab] + __logf(sum[ab]);
+                l2[b] = lse;
+                const long long t = tg[ab];
+                if (t >= 0 && t < K) {
+                    if (counting) {
+                        atomicAdd(&hist[K + (int)t], 1u);
+                        if (arg[ab] == (int)t) atomicAdd(&hist[(int)t], 1u);
+                    }
+                    if (t != d.ignore_index) { loss += lse - tl[ab]; cnt += 1.0f; }
+                }
+            }
+            *reinterpret_cast<f32x2 *>(d.lse + o0 + (long long)a * Wo) = l2;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        loss += __shfl_xor(loss, o);
+        cnt += __shfl_xor(cnt, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = loss;
+        red[1][threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[0][w]; b += red[1][w]; }
+        d.partial[2 * (long long)blockIdx.x + 0] = a;
+        d.partial[2 * (long long)blockIdx.x + 1] = b;
+    }
+    if (counting && threadIdx.x < 2 * K) d.cpartial[(long long)blockIdx.x * 2 * K + threadIdx.x] = hist[threadIdx.x];
 }
 
 struct CeBwdDesc {

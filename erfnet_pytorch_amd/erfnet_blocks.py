@@ -210,7 +210,8 @@ class OutputConvTranspose(nn.ConvTranspose2d):
 
     def forward(self, input, output_size=None):
         if input.is_cuda:
-            return hipf.outconv(input, self.weight, self.bias)
+            # (a DataParallel replica's output is gathered in C++, which a deferred tensor cannot notice)
+            return hipf.outconv(input, self.weight, self.bias, allow_lazy=not getattr(self, "_is_replica", False))
         return super().forward(input, output_size)
 
     def argmax(self, input):

@@ -6,6 +6,7 @@ shape stays [N,C,H,W], i.e. ``torch.channels_last``); the classifier logits leav
 transposed convolution NCHW-contiguous so that torch's loss / argmax read them directly.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -698,6 +699,100 @@ def set_loss_handover(enabled):
     return old
 
 
+# Deferred logits.  In the reference's training loop the logits have one reader, the loss
+# (train/main.py:327,333: outputs = model(inputs); loss = criterion(outputs, targets)), and with the
+# loss hand-over even the backward pass recomputes them in registers — writing 4*K bytes per output
+# pixel only to read them once is the single largest transfer of the step.  So, while autograd
+# records, the output convolution returns a tensor whose memory is allocated but not yet filled
+# (_LazyLogits): CrossEntropyLoss2d recognises it and runs erf_outconv_ce_forward on the convolution's
+# INPUT instead; anything else that touches the tensor — any torch function or Tensor method that is
+# not a pure metadata query — first runs the convolution kernel into that memory, after which it is
+# an ordinary tensor.  What cannot be intercepted is code that reads the memory without going through
+# torch's Python API (DataParallel's gather of several replicas runs in C++): replicas therefore get
+# ordinary logits (erfnet_blocks.OutputConvTranspose), and set_lazy_logits(False) turns it off.
+_LAZY_LOGITS = os.environ.get("ERFNET_NO_LAZY_LOGITS", "0") in ("", "0")       # (the variable: A/B runs)
+
+
+def set_lazy_logits(enabled):
+    """Switch the deferred logits (see above) on or off; returns the previous setting."""
+    global _LAZY_LOGITS
+    old, _LAZY_LOGITS = _LAZY_LOGITS, bool(enabled)
+    return old
+
+
+def _tensor_args(args, kwargs):
+    stack = list(args) + list(kwargs.values())
+    while stack:
+        a = stack.pop()
+        if isinstance(a, torch.Tensor):
+            yield a
+        elif isinstance(a, (list, tuple)):
+            stack.extend(a)
+        elif isinstance(a, dict):
+            stack.extend(a.values())
+
+
+class _LazyLogits(torch.Tensor):
+    """Logits of the output convolution whose kernel has not run yet (``_erf_lazy`` holds what it needs)."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func not in _LAZY_METADATA:
+            for a in _tensor_args(args, kwargs):
+                if type(a) is _LazyLogits:
+                    _materialize_logits(a)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
+def _metadata_queries():
+    t = torch.Tensor
+    props = ("shape", "dtype", "device", "requires_grad", "grad_fn", "is_leaf", "ndim", "is_cuda", "layout",
+             "_version", "retains_grad", "grad", "is_sparse", "is_quantized", "is_meta", "names", "output_nr")
+    fns = {getattr(t, n).__get__ for n in props if hasattr(t, n) and hasattr(getattr(t, n), "__get__")}
+    for n in ("size", "dim", "stride", "numel", "nelement", "is_contiguous", "element_size", "storage_offset",
+              "is_floating_point", "is_complex", "get_device", "register_hook", "retain_grad", "__hash__",
+              "is_shared", "is_pinned", "has_names", "__len__", "ndimension", "type"):
+        if hasattr(t, n):
+            fns.add(getattr(t, n))
+    return fns
+
+
+_LAZY_METADATA = _metadata_queries()
+
+
+def _lazy_pending(t):
+    """The deferred-convolution record of ``t`` if its kernel has not run yet, else None."""
+    if type(t) is not _LazyLogits:
+        return None
+    rec = t.__dict__.get("_erf_lazy")
+    return rec if (rec is not None and not rec["done"]) else None
+
+
+def _materialize_logits(t):
+    rec = _lazy_pending(t)
+    if rec is None:
+        return
+    rec["done"] = True
+    x, wb = rec["x"], rec["wb"]
+    n, cin, h, wd = x.shape
+    ncls = rec["ncls"]
+    nw = cin * ncls * 4
+    wq, bq = wb[:nw], (wb[nw:] if rec["has_bias"] else None)
+    with torch._C.DisableTorchFunctionSubclass():
+        ptr = torch.Tensor.data_ptr(t)
+    lib = _lib.lib()
+    with _dev_ctx(x):
+        if x.dtype == torch.bfloat16:
+            _lib.check(lib.erf_outconv_forward_bf16(_p(x), _p(wq), _p(bq), C.c_void_p(ptr), 0, n, cin, h, wd, ncls, 0,
+                                                    _stream(x)))
+        else:
+            _lib.check(lib.erf_outconv_forward(_p(x), _p(wq), _p(bq), C.c_void_p(ptr), n, cin, h, wd, ncls, 0,
+                                               _stream(x)))
+    rec["x"] = rec["wb"] = None
+
+
 class _LossToken:
     __slots__ = ("pending", "zero")
 
@@ -711,14 +806,21 @@ class _LossToken:
 
 class _OutConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, loss_token):
+    def forward(ctx, x, w, b, loss_token, lazy):
         lib = _lib.lib()
         ctx.in_token = _input_token(x)
         x = _nhwc(x)
         n, cin, h, wd = x.shape
         ncls = w.shape[1]
         wq, bq = _param(w), _param(b)
-        y = _outconv_call(x, wq, bq, n, cin, h, wd, ncls, 0, False)
+        if lazy:
+            # memory now, contents when somebody other than the loss asks for them (see _LazyLogits);
+            # the parameters are copied: an optimiser step may come between now and then
+            y = torch.empty((n, ncls, 2 * h, 2 * wd), dtype=torch.float32, device=x.device).as_subclass(_LazyLogits)
+            wb = torch.cat([wq.reshape(-1), bq.reshape(-1)]) if bq is not None else wq.reshape(-1).clone()
+            y._erf_lazy = dict(done=False, x=x, wb=wb, ncls=ncls, has_bias=bq is not None)
+        else:
+            y = _outconv_call(x, wq, bq, n, cin, h, wd, ncls, 0, False)
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(x, wq, bq)
             ctx.has_bias = b is not None
@@ -754,6 +856,7 @@ class _OutConv(torch.autograd.Function):
                 # deposited loss gradients are materialised and summed with what autograd delivered
                 total = None if tok.is_stand_in(gy) else gy.float()
                 for target, lse, stats, gl, ignore_index, logits in pending:
+                    _materialize_logits(logits)
                     g = _cross_entropy_grad(logits, target, lse, stats, gl, ignore_index)
                     total = g if total is None else total + g
                 gy = total
@@ -764,7 +867,7 @@ class _OutConv(torch.autograd.Function):
                 _lib.check(_fn("erf_outconv_backward", x)(_p(x), _p(wq), _p(gy), _p(dx), _p(dw), _p(db), n, cin, h,
                                                           wd, ncls, flags, _p(ws), ws.numel(), _stream(x)))
         dw, db = _match_params(_deliver(tg), ctx.params)
-        return _hand_over(ctx, dx), dw, (db if ctx.has_bias else None), None
+        return _hand_over(ctx, dx), dw, (db if ctx.has_bias else None), None, None
 
 
 def _outconv_call(x, wq, bq, n, cin, h, wd, ncls, softmax, bf16_out):
@@ -784,16 +887,21 @@ def _outconv_call(x, wq, bq, n, cin, h, wd, ncls, softmax, bf16_out):
     return y
 
 
-def outconv(x, w, b):
+def outconv(x, w, b, allow_lazy=True):
     """nn.ConvTranspose2d(Cin, ncls, 2, stride=2) (train/net_classification.py:56,64) on the GPU.
     Returns NCHW-contiguous logits.  bf16 activations: the logits are fp32 while an autograd graph is
     being built (they feed the loss), bf16 under torch.no_grad() (half the bytes of the largest
-    tensor of the network)."""
+    tensor of the network).  While an autograd graph is being built the logits may be deferred
+    (_LazyLogits above) unless ``allow_lazy`` is False."""
     if torch.is_grad_enabled():
         tok = _LossToken(x.device) if _LOSS_HANDOVER else None
-        y = _OutConv.apply(x, w, b, tok)
+        lazy = bool(tok is not None and _LAZY_LOGITS and allow_lazy and w.shape[1] <= 32 and x.shape[1] == 16 and
+                    (x.requires_grad or w.requires_grad))
+        y = _OutConv.apply(x, w, b, tok, lazy)
         if tok is not None and y.requires_grad:
             y._erf_loss_token = tok
+        elif lazy:
+            _materialize_logits(y)
         return y
     x = _nhwc(x)
     n, cin, h, wd = x.shape
@@ -882,15 +990,40 @@ class _CrossEntropy(torch.autograd.Function):
         if tuple(target.shape) != (n, h, wd):
             raise ValueError(f"cross_entropy: target shape {tuple(target.shape)} does not match logits "
                              f"{tuple(logits.shape)}")
-        x = logits.contiguous()
         tg = target.contiguous()
-        stats = torch.empty(2, dtype=torch.float32, device=x.device)
-        lse = torch.empty((n, h, wd), dtype=torch.float32, device=x.device)
-        ws = _workspace(x, n * h * wd, 1)
+        dev = logits.device
+        stats = torch.empty(2, dtype=torch.float32, device=dev)
+        lse = torch.empty((n, h, wd), dtype=torch.float32, device=dev)
         # With the reference's ignore_index (-1: exactly the negative labels are unlabelled) the same
         # pass also counts what its accuracy metrics need; they find the counts on the logits.
-        counts = torch.empty((2, k), dtype=torch.int64, device=x.device) if (k <= 32 and int(ignore_index) == -1) \
+        counts = torch.empty((2, k), dtype=torch.int64, device=dev) if (k <= 32 and int(ignore_index) == -1) \
             else None
+        rec = _lazy_pending(logits)
+        tok = logits.__dict__.get("_erf_loss_token") if rec is not None else None
+        if rec is not None and tok is not None and _LOSS_HANDOVER and ctx.needs_input_grad[0] and \
+                tg.data_ptr() % 16 == 0:
+            # deferred logits whose gradient will go through the hand-over: loss, log-sum-exp and counts
+            # straight from the output convolution's input (erf_outconv_ce_forward)
+            xin, wb = rec["x"], rec["wb"]
+            _, cin, hi, wi = xin.shape
+            nw = cin * k * 4
+            wq, bq = wb[:nw], (wb[nw:] if rec["has_bias"] else None)
+            ws = _workspace(xin, n * hi * wi, 2 * k + 2)
+            with _dev_ctx(xin):
+                _lib.check(_fn("erf_outconv_ce_forward", xin)(_p(xin), _p(wq), _p(bq), _p(tg), _p(stats), _p(lse),
+                                                              _p(counts), n, cin, hi, wi, k, int(ignore_index),
+                                                              _p(ws), ws.numel(), _stream(xin)))
+            if counts is not None:
+                logits._erf_acc_cache = (target.data_ptr(), target._version, tuple(target.shape),
+                                         torch.Tensor._version.__get__(logits), counts)
+            ctx.save_for_backward(tg, lse, stats)
+            ctx.lazy_logits = logits
+            ctx.ignore_index = int(ignore_index)
+            ctx.loss_token = tok
+            return stats[0]
+        _materialize_logits(logits)
+        x = logits.contiguous()
+        ws = _workspace(x, n * h * wd, 1)
         with _dev_ctx(x):
             if counts is None:
                 _lib.check(lib.erf_cross_entropy_forward(_p(x), _p(tg), _p(stats), _p(lse), n, k, h, wd,
@@ -901,6 +1034,7 @@ class _CrossEntropy(torch.autograd.Function):
                                                                 _stream(x)))
                 logits._erf_acc_cache = (target.data_ptr(), target._version, tuple(target.shape), logits._version,
                                          counts)
+        ctx.lazy_logits = None
         if ctx.needs_input_grad[0]:
             ctx.save_for_backward(x, tg, lse, stats)
             ctx.ignore_index = int(ignore_index)
@@ -912,7 +1046,11 @@ class _CrossEntropy(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, tg, lse, stats = ctx.saved_tensors
+        if ctx.lazy_logits is not None:
+            tg, lse, stats = ctx.saved_tensors
+            x = ctx.lazy_logits         # (filled only if the gradient has to be materialised after all)
+        else:
+            x, tg, lse, stats = ctx.saved_tensors
         gy = gy.to(torch.float32).reshape(1).contiguous()
         tok = ctx.loss_token
         if tok is not None and _LOSS_HANDOVER:
@@ -934,6 +1072,7 @@ class _CrossEntropy(torch.autograd.Function):
                             "the graph to get d(loss)/d(logits) itself")
             torch.autograd.Variable._execution_engine.queue_callback(settle)
             return tok.zero.expand(x.shape), None, None
+        _materialize_logits(x)
         return _cross_entropy_grad(x, tg, lse, stats, gy, ctx.ignore_index), None, None
 
 

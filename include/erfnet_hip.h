@@ -217,6 +217,17 @@ int erf_outconv_ce_backward(const float *x, const float *w, const float *b, cons
                             float *db, int N, int Cin, int H, int W, int ncls, long long ignore_index,
                             int flags, void *ws, size_t ws_bytes, void *stream);
 
+/* Forward of the training loop's `criterion(model(x), targets)` THROUGH the output convolution
+ * (train/main.py:327,333: outputs = model(inputs); loss = criterion(outputs, targets), with
+ * train/net_classification.py:56,64 producing the logits): equals erf_outconv_forward followed by
+ * erf_cross_entropy_forward[_counts] on its logits, but the logits are formed in registers and never
+ * written — the loop reads them for nothing else, and erf_outconv_ce_backward recomputes them.
+ * stats / lse / counts as erf_cross_entropy_forward_counts produces them (lse bit for bit; the loss
+ * to the rounding of a different summation order); counts may be NULL.  1 <= ncls <= 32. */
+int erf_outconv_ce_forward(const float *x, const float *w, const float *b, const long long *target,
+                           float *stats, float *lse, long long *counts, int N, int Cin, int H, int W,
+                           int ncls, long long ignore_index, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- plain nn.Conv2d on NHWC tensors (Encoder.output_conv 1x1, eval/erfnet.py:85,93-94;
  *      LadderBlock's 3x3 conv, train/erfnet_blocks.py:145,151-154) -----------------------------
  * Square kernel k in {1,3}, stride 1, padding (k-1)/2.  relu != 0 fuses F.relu (no BN). */
@@ -403,6 +414,9 @@ int erf_outconv_argmax_bf16(const void *x, const float *w, const float *b, long 
 int erf_outconv_backward_bf16(const void *x, const float *w, const float *gy, void *dx, float *dw,
                               float *db, int N, int Cin, int H, int W, int ncls, int flags, void *ws,
                               size_t ws_bytes, void *stream);
+int erf_outconv_ce_forward_bf16(const void *x, const float *w, const float *b, const long long *target,
+                                float *stats, float *lse, long long *counts, int N, int Cin, int H, int W,
+                                int ncls, long long ignore_index, void *ws, size_t ws_bytes, void *stream);
 int erf_outconv_ce_backward_bf16(const void *x, const float *w, const float *b, const long long *target,
                                  const float *lse, const float *stats, const float *gy, void *dx, float *dw,
                                  float *db, int N, int Cin, int H, int W, int ncls, long long ignore_index,

@@ -171,10 +171,11 @@ def test_block_bf16_against_golden(name, monkeypatch):
         xs.append(_t(x).to(BF).requires_grad_(True))
     before = _lib.launch_count()
     y = mod(*xs)
-    assert _lib.launch_count() > before
     if c["kind"] != "outconv":
         assert y.dtype == BF
-    gu.check(BLK, f"{name}/y", y.detach().float().cpu().numpy(), 1e-5, 0.0, what=f"{name}/y bf16", scale_rtol=1e-2)
+    yv = y.detach().float().cpu().numpy()       # (the output convolution's logits are written on first use)
+    assert _lib.launch_count() > before
+    gu.check(BLK, f"{name}/y", yv, 1e-5, 0.0, what=f"{name}/y bf16", scale_rtol=1e-2)
     gy = _t(gu.det_normal(f"{name}.gy", tuple(y.shape))).to(y.dtype)
     y.backward(gy)
     for i, x in enumerate(xs):

@@ -94,8 +94,9 @@ def test_block_against_golden(name, monkeypatch):
         xs.append(t(x).requires_grad_(True))
     before = launches()
     y = mod(*xs)
+    yv = y.detach().cpu().numpy()               # (the output convolution's logits are written on first use)
     assert launches() > before, "no HIP kernel was launched"
-    chk_fwd(name, "y", y.detach().cpu().numpy())
+    chk_fwd(name, "y", yv)
     gy = t(gu.det_normal(f"{name}.gy", tuple(y.shape)))
     y.backward(gy)
     for i, x in enumerate(xs):
@@ -590,12 +591,130 @@ def test_loss_hand_over_matches_separate_kernels(mode, dtype, ncls):
         plain = _loss_head_run(mode, dtype, ncls)
     finally:
         hipf.set_loss_handover(old)
-    assert fused[0] == plain[0]
+    # (the deferred logits evaluate the loss in erf_outconv_ce_forward, whose block sums group the pixels
+    # differently from erf_cross_entropy_forward's: equal to a few fp32 roundings)
+    assert abs(fused[0] - plain[0]) <= 2e-6 * abs(plain[0])
     if mode in ("plain", "scaled"):
         assert fused[2] < plain[2]          # fewer launches: the fused kernel really ran
     tol = 2e-5 if dtype == torch.float32 else 1e-2      # bf16: dx is rounded to bf16 on both sides
     for nm, u, v in zip(("dx", "dw", "db"), fused[1], plain[1]):
         gu.check_arrays(u, v, 1e-7, 1e-5, what=f"{mode}/{nm}", scale_rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ncls,n,h,w", [(20, 2, 24, 40), (7, 1, 9, 13), (32, 3, 16, 16), (1, 2, 8, 8)])
+def test_outconv_ce_forward_against_the_two_kernels(dtype, ncls, n, h, w):
+    """erf_outconv_ce_forward (output convolution + CrossEntropyLoss + accuracy counts, the logits never
+    stored; train/main.py:327,333,343-347) through the raw C ABI against erf_outconv_forward followed by
+    erf_cross_entropy_forward_counts: the log-sum-exp bit for bit, the counts exactly, loss and pixel
+    count to fp32 rounding; and the loss against torch's own on the stored logits."""
+    import ctypes as C
+    from erfnet_pytorch_amd import _lib
+    lib = _lib.lib()
+    p = lambda q: None if q is None else C.c_void_p(q.data_ptr())
+    sfx = "_bf16" if dtype == torch.bfloat16 else ""
+    x = t(np.maximum(gu.det_normal("ocef.x", (n, 16, h, w)), 0)).to(dtype).contiguous(memory_format=torch.channels_last)
+    wt = t(0.3 * gu.det_normal("ocef.w", (16, ncls, 2, 2)))
+    b = t(0.1 * gu.det_normal("ocef.b", (ncls,)))
+    lab = t(gu.det_labels("ocef.lab", (n, 2 * h, 2 * w), -1, ncls))
+    if ncls > 2:
+        lab[0, 0, :4] = ncls + 3            # labels outside [0, K) that are not ignore_index count as unlabelled
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    wsb = torch.empty(int(lib.erf_workspace_bytes(n * 4 * h * w, 2 * ncls + 2)), dtype=torch.uint8, device=DEV)
+    logits = torch.empty(n, ncls, 2 * h, 2 * w, device=DEV)
+    if dtype == torch.bfloat16:
+        _lib.check(lib.erf_outconv_forward_bf16(p(x), p(wt), p(b), p(logits), 0, n, 16, h, w, ncls, 0, st))
+    else:
+        _lib.check(lib.erf_outconv_forward(p(x), p(wt), p(b), p(logits), n, 16, h, w, ncls, 0, st))
+    s0, l0, c0 = torch.zeros(2, device=DEV), torch.zeros(n, 2 * h, 2 * w, device=DEV), torch.zeros(2, ncls, dtype=torch.int64, device=DEV)
+    _lib.check(lib.erf_cross_entropy_forward_counts(p(logits), p(lab), p(s0), p(l0), p(c0), n, ncls, 2 * h, 2 * w, -1,
+                                                    p(wsb), wsb.numel(), st))
+    s1, l1, c1 = torch.zeros(2, device=DEV), torch.zeros(n, 2 * h, 2 * w, device=DEV), torch.zeros(2, ncls, dtype=torch.int64, device=DEV)
+    before = launches()
+    _lib.check(getattr(lib, "erf_outconv_ce_forward" + sfx)(p(x), p(wt), p(b), p(lab), p(s1), p(l1), p(c1), n, 16, h, w,
+                                                           ncls, -1, p(wsb), wsb.numel(), st))
+    torch.cuda.synchronize()
+    assert launches() == before + 3
+    assert torch.equal(l0, l1)
+    assert torch.equal(c0, c1)
+    assert float(s0[1]) == float(s1[1]) > 0
+    assert abs(float(s0[0]) - float(s1[0])) <= 2e-6 * abs(float(s0[0]))
+    valid = (lab >= 0) & (lab < ncls)
+    ref = torch.nn.functional.cross_entropy(logits.double(), torch.where(valid, lab, torch.full_like(lab, -1)),
+                                            ignore_index=-1)
+    assert abs(float(ref) - float(s1[0])) <= 1e-5 * max(1.0, abs(float(ref)))
+    # without counts
+    s2, l2 = torch.zeros(2, device=DEV), torch.zeros(n, 2 * h, 2 * w, device=DEV)
+    _lib.check(getattr(lib, "erf_outconv_ce_forward" + sfx)(p(x), p(wt), p(b), p(lab), p(s2), p(l2), None, n, 16, h, w,
+                                                           ncls, -1, p(wsb), wsb.numel(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s2) and torch.equal(l1, l2)
+
+
+def test_deferred_logits_are_ordinary_logits_to_everybody_but_the_loss():
+    """While autograd records, the output convolution defers its kernel (functional._LazyLogits): the
+    loss never needs the logits in memory, anything else gets them on first touch — the values of
+    THAT forward pass, even when the parameters have moved since."""
+    from erfnet_pytorch_amd import functional as hipf
+    from erfnet_pytorch_amd.evaluation_functions import ClassificationAccuracy, CrossEntropyLoss2d
+    shape, ncls = (2, 16, 12, 20), 20
+    x = t(np.maximum(gu.det_normal("losshead.x", shape), 0)).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    wt = t(0.3 * gu.det_normal("losshead.w", (16, ncls, 2, 2))).requires_grad_(True)
+    b = t(0.1 * gu.det_normal("losshead.b", (ncls,))).requires_grad_(True)
+    lab = t(gu.det_labels("losshead.lab", (2, 24, 40), -1, ncls))
+    with torch.no_grad():
+        eager = hipf.outconv(x, wt, b).clone()
+    # 1. loss only: no logits kernel at all
+    n0 = launches()
+    y = hipf.outconv(x, wt, b)
+    assert type(y) is hipf._LazyLogits and tuple(y.shape) == (2, ncls, 24, 40) and y.requires_grad
+    loss = CrossEntropyLoss2d()(y, lab)
+    acc = ClassificationAccuracy()(y, lab)           # served from the counts the loss left behind
+    loss.backward()
+    n_lazy = launches() - n0
+    assert hipf._lazy_pending(y) is not None         # still never written
+    ref_acc = float(((eager.argmax(1) == lab) & (lab >= 0)).sum()) / float((lab >= 0).sum())
+    assert abs(float(acc) - ref_acc) < 1e-6
+    got = [v.grad.clone() for v in (x, wt, b)]
+    # 2. the parameters move, then somebody looks at the logits of that forward pass
+    keep = (wt.detach().clone(), b.detach().clone())
+    with torch.no_grad():
+        wt.mul_(0.5)
+        b.add_(1.0)
+    assert torch.equal(y.detach(), eager)
+    assert hipf._lazy_pending(y) is None
+    assert torch.equal(y.max(1)[1], eager.max(1)[1])
+    with torch.no_grad():
+        wt.copy_(keep[0])
+        b.copy_(keep[1])
+    # 3. the same step with eager logits: same gradients, more launches
+    for v in (x, wt, b):
+        v.grad = None
+    old = hipf.set_lazy_logits(False)
+    try:
+        n0 = launches()
+        y2 = hipf.outconv(x, wt, b)
+        assert type(y2) is torch.Tensor
+        loss2 = CrossEntropyLoss2d()(y2, lab)
+        ClassificationAccuracy()(y2, lab)
+        loss2.backward()
+        n_eager = launches() - n0
+    finally:
+        hipf.set_lazy_logits(old)
+    assert n_lazy < n_eager
+    assert abs(float(loss) - float(loss2)) <= 2e-6 * abs(float(loss2))
+    for nm, u, v in zip(("dx", "dw", "db"), got, (x, wt, b)):
+        assert torch.equal(u, v.grad), nm
+    # 4. a second consumer of the logits (the consistency loss of the mean-teacher loop) materialises them
+    for v in (x, wt, b):
+        v.grad = None
+    y3 = hipf.outconv(x, wt, b)
+    total = CrossEntropyLoss2d()(y3, lab) + 0.1 * (y3 * y3).mean()
+    total.backward()
+    y4 = eager.clone().requires_grad_(True)
+    ref_total = torch.nn.functional.cross_entropy(y4, lab, ignore_index=-1) + 0.1 * (y4 * y4).mean()
+    assert abs(float(total) - float(ref_total)) <= 1e-5 * abs(float(ref_total))
 
 
 def test_gradient_of_the_logits_themselves_is_refused_loudly_under_hand_over():
