@@ -2421,9 +2421,14 @@ static int outconv_ce_forward_impl(int dt, const void *x, const float *w, const 
     const long long blocks = (M + 255) / 256;
     float *partial = ar.floats((size_t)blocks * 2);
     unsigned *cpartial = counts ? (unsigned *)ar.take((size_t)blocks * 2 * ncls * sizeof(unsigned)) : nullptr;
-    if (!partial || (counts && !cpartial)) return fail("output ConvTranspose2d + loss forward: workspace too small");
-    OutConvCeFwdDesc d = {x, w, b, target, lse, partial, cpartial, N, H, W, ncls, ignore_index};
-    BY_DT(dt, (outconv_ce_fwd_kernel<T><<<(unsigned)blocks, 256, 0, st>>>(d)));
+    float *wpk = ar.floats((size_t)ncls * 4 * OC_CIN + ncls);
+    if (!partial || !wpk || (counts && !cpartial)) return fail("output ConvTranspose2d + loss forward: workspace too small");
+    OutConvCeFwdDesc d = {x, w, b, wpk, target, lse, partial, cpartial, N, H, W, ncls, ignore_index};
+    outconv_ce_pack_kernel<<<1, 256, 0, st>>>(d);
+    CHECK_LAUNCH("outconv_ce_pack_kernel");
+    if (ncls == 20) BY_DT(dt, (outconv_ce_fwd_kernel<T, 20><<<(unsigned)blocks, 256, 0, st>>>(d)));
+    else if (ncls == 19) BY_DT(dt, (outconv_ce_fwd_kernel<T, 19><<<(unsigned)blocks, 256, 0, st>>>(d)));
+    else BY_DT(dt, (outconv_ce_fwd_kernel<T, 0><<<(unsigned)blocks, 256, 0, st>>>(d)));
     CHECK_LAUNCH("outconv_ce_fwd_kernel");
     ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
     CHECK_LAUNCH("ce_reduce_kernel");

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float *partial, in
 struct OutConvCeFwdDesc {
     const void *x;              // NHWC [N][H][W][16], storage type T
     const float *w, *b;         // [16][K][2][2], [K]
+    float *wpk;                 // workspace: the weights as [K][a][b][16] followed by the K biases
     const long long *target;    // [N][2H][2W]
     float *lse;                 // [N][2H][2W]
     float *partial;             // [blocks][2]
@@ -165,19 +166,31 @@ struct OutConvCeFwdDesc {
     long long ignore_index;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void outconv_ce_fwd_kernel(const OutConvCeFwdDesc d)
+// Weights in the order the loss kernel walks them, biases behind: wpk[(o*16 + c)*4 + ab], wpk[K*64 + o].
+__global__ __launch_bounds__(256) void outconv_ce_pack_kernel(const OutConvCeFwdDesc d)
 {
-    __shared__ __attribute__((aligned(16))) float ws[OC_MAX_NCLS * 4 * OC_CIN];
-    __shared__ float bs[OC_MAX_NCLS];
-    __shared__ float red[2][4];
-    __shared__ unsigned hist[2 * CE_MAX_K];
     const int K = d.K;
     for (int i = threadIdx.x; i < K * 4 * OC_CIN; i += 256) {
-        const int c = i % OC_CIN, ab = (i / OC_CIN) % 4, o = i / (OC_CIN * 4);
-        ws[i] = d.w[(c * K + o) * 4 + ab];
+        const int ab = i % 4, c = (i / 4) % OC_CIN, o = i / (OC_CIN * 4);
+        d.wpk[i] = d.w[(c * K + o) * 4 + ab];
     }
-    for (int i = threadIdx.x; i < K; i += 256) bs[i] = d.b ? d.b[i] : 0.0f;
+    for (int i = threadIdx.x; i < K; i += 256) d.wpk[K * 4 * OC_CIN + i] = d.b ? d.b[i] : 0.0f;
+}
+
+// The weights are the same for every thread: they are read through the constant address space, i.e.
+// by scalar loads into scalar registers that the multiply-adds take as an operand — no LDS traffic
+// (one LDS read per four multiply-adds bounded the first version of this kernel at 92 us).
+typedef const __attribute__((address_space(4))) float oc_cfloat;
+
+// KC > 0: the class count as a compile-time constant (must equal d.K); 0: any count up to 32.
+template <typename T, int KC>
+__global__ __launch_bounds__(256) void outconv_ce_fwd_kernel(const OutConvCeFwdDesc d)
+{
+    __shared__ float red[2][4];
+    __shared__ unsigned hist[2 * CE_MAX_K];
+    const int K = KC > 0 ? KC : d.K;
+    oc_cfloat *ws = (oc_cfloat *)(uintptr_t)d.wpk;
+    oc_cfloat *bs = ws + K * 4 * OC_CIN;
     const bool counting = d.cpartial != nullptr;
     if (threadIdx.x < 2 * CE_MAX_K) hist[threadIdx.x] = 0;
     __syncthreads();
@@ -208,13 +221,19 @@ __global__ __launch_bounds__(256) void outconv_ce_fwd_kernel(const OutConvCeFwdD
         int arg[4];
 #pragma unroll
         for (int ab = 0; ab < 4; ++ab) { mx[ab] = -INFINITY; best[ab] = 0.0f; arg[ab] = 0; tl[ab] = 0.0f; }
-        for (int o = 0; o < K; ++o)
+        auto logits4 = [&](int o, float (&r4)[4]) __attribute__((always_inline)) {
+            oc_cfloat *w0 = &ws[o * 4 * OC_CIN];
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) r4[ab] = bs[o];
+#pragma unroll
+            for (int c = 0; c < OC_CIN; ++c)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) r4[ab] = fmaf(xv[c], w0[c * 4 + ab], r4[ab]);
+        };
+        auto first_pass = [&](int o, const float (&r4)[4]) __attribute__((always_inline)) {
 #pragma unroll
             for (int ab = 0; ab < 4; ++ab) {
-                float r = bs[o];
-                const float *w0 = &ws[(o * 4 + ab) * OC_CIN];
-#pragma unroll
-                for (int c = 0; c < OC_CIN; ++c) r = fmaf(xv[c], w0[c], r);
+                const float r = r4[ab];
                 mx[ab] = o == 0 ? r : fmaxf(mx[ab], r);
                 // first largest value, NaN wins: torch's argmax
                 const bool take = o == 0 || r > best[ab] || (r != r && best[ab] == best[ab]);
@@ -222,17 +241,35 @@ __global__ __launch_bounds__(256) void outconv_ce_fwd_kernel(const OutConvCeFwdD
                 arg[ab] = take ? o : arg[ab];
                 tl[ab] = (long long)o == tg[ab] ? r : tl[ab];
             }
-        // second pass: the sum of exponentials in class order (the order of ce_fwd_kernel)
+        };
         float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int o = 0; o < K; ++o)
+        if constexpr (KC > 0) {
+            // the class count is a compile-time constant: every logit stays in a register, one pass of
+            // multiply-adds; maxima and sums are formed in class order as in the two-pass form
+            float lg[KC][4];
 #pragma unroll
-            for (int ab = 0; ab < 4; ++ab) {
-                float r = bs[o];
-                const float *w0 = &ws[(o * 4 + ab) * OC_CIN];
-#pragma unroll
-                for (int c = 0; c < OC_CIN; ++c) r = fmaf(xv[c], w0[c], r);
-                sum[ab] += __expf(r - mx[ab]);
+            for (int o = 0; o < KC; ++o) {
+                logits4(o, lg[o]);
+                first_pass(o, lg[o]);
             }
+#pragma unroll
+            for (int o = 0; o < KC; ++o)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) sum[ab] += __expf(lg[o][ab] - mx[ab]);
+        } else {
+            for (int o = 0; o < K; ++o) {
+                float r4[4];
+                logits4(o, r4);
+                first_pass(o, r4);
+            }
+            // second pass: the sum of exponentials in class order (the order of ce_fwd_kernel)
+            for (int o = 0; o < K; ++o) {
+                float r4[4];
+                logits4(o, r4);
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) sum[ab] += __expf(r4[ab] - mx[ab]);
+            }
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             f32x2 l2;
