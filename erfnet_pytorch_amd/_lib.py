@@ -36,7 +36,8 @@ class BnStruct(C.Structure):
 class Nb1dBlockStruct(C.Structure):
     """Mirror of ``erf_nb1d_block_t``."""
     _fields_ = [("w", vp * 4), ("b", vp * 4), ("bn1", C.POINTER(BnStruct)), ("bn2", C.POINTER(BnStruct)),
-                ("drop_scale", vp), ("dil", C.c_int), ("y", vp), ("save", C.POINTER(vp))]
+                ("drop_scale", vp), ("dil", C.c_int), ("y", vp), ("save", C.POINTER(vp)),
+                ("sign_bits", C.POINTER(vp)), ("sign_bits_written", C.POINTER(C.c_uint))]
 
 
 def sources():
@@ -86,6 +87,10 @@ _PROTOS = {
                                     C.c_int, vp, C.POINTER(vp), vp, vp, C.POINTER(vp),
                                     C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "erf_nb1d_backward_bits": (C.c_int, [vp, C.POINTER(vp), C.POINTER(BnStruct), C.POINTER(BnStruct), vp,
+                                         C.c_int, vp, C.POINTER(vp), C.POINTER(vp), vp, vp, C.POINTER(vp),
+                                         C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_upsampler_forward": (C.c_int, [vp, vp, vp, C.POINTER(BnStruct), vp, vp, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "erf_upsampler_backward": (C.c_int, [vp, vp, C.POINTER(BnStruct), vp, vp, vp, vp, vp, vp, vp, vp,
@@ -139,7 +144,7 @@ BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
 OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16, OPT_PAIR16, OPT_LINE2, OPT_SPLIT_BF16, OPT_CONV16_ROWS, OPT_X3_ROLL = 1, 2, 3, 4, 5, 6, 7, 8
 
 EXPORTS = tuple(_PROTOS)
-ABI_VERSION = 102                         # ERF_ABI_VERSION of include/erfnet_hip.h
+ABI_VERSION = 103                         # ERF_ABI_VERSION of include/erfnet_hip.h
 
 
 def lib():

@@ -59,6 +59,10 @@ struct Epilogue {
     const void *mask;
     int mask_C, mask_coff;
     int relu;
+    // ReLU masks as bit tensors (line_x3r_kernel only; both optional): one 32-bit word per pixel and
+    // group of 32 channels, bit c % 32 of word [pixel][c / 32] set iff the value is > 0.
+    unsigned *bits_out;         // written for this launch's output (after every other epilogue step)
+    const unsigned *mask_bits;  // read in place of `mask` (same meaning: keep the value where the bit is set)
 };
 
 // Implicit-GEMM convolution: out[pix(m)][co] = epi( sum_t sum_k in[src(m,t)][k] * W[t][k][co] ).

@@ -302,6 +302,25 @@ int line_x3_grid(const IgemmDesc &d)
     const int slots = line_x3_slots(d.K);
     return (int)(ntiles < slots ? ntiles : slots);
 }
+// Whether a launch of this geometry goes to the rolling kernel (line_x3r_kernel): 64-pixel tiles,
+// taps {-dil, 0, +dil} in either order, whole tap chains per image, no output statistics.
+// ERFNET_X3R_ONLY=64 / 128 keeps it to that width (experiments).
+bool line_x3r_takes(const LineDesc &ld, int NC)
+{
+    static int only = -1;
+    if (only < 0) { const char *e = getenv("ERFNET_X3R_ONLY"); only = e ? atoi(e) : 0; }
+    const int dil = ld.s1[0] < 0 ? -ld.s1[0] : ld.s1[0];
+    return g_sw_x3r.on() && !ld.stats && line_x3_tile(NC, ld.L) == 64 && dil > 0 && ld.s1[1] == 0 &&
+           ld.s1[2] == -ld.s1[0] && ld.lines_per_img % dil == 0 && (!only || only == NC);
+}
+// The same question for a planned convolution (only the rolling kernel reads and writes mask bits).
+bool igemm_on_x3r(const IgemmDesc &d)
+{
+    LineDesc ld;
+    if (d.cfg != kCfgLineX3 || !line_geometry(d, ld)) return false;
+    ld.stats = d.bn_partial;
+    return line_x3r_takes(ld, d.K);
+}
 int run_line_x3(LineDesc ld, int NC, hipStream_t st)
 {
     // 64 channels: two independent blocks per CU (each fills the other's barrier, latency and
@@ -312,18 +331,13 @@ int run_line_x3(LineDesc ld, int NC, hipStream_t st)
     if (ntiles <= 0) return 0;
     const int slots = line_x3_slots(NC);
     const unsigned grid = (unsigned)(ntiles < slots ? ntiles : slots);
-    {   // the rolling kernel: 64-pixel tiles, taps {-dil, 0, +dil} (either order), whole chains per image
-        const int dil = ld.s1[0] < 0 ? -ld.s1[0] : ld.s1[0];
-        static int only = -1;       // ERFNET_X3R_ONLY=64 / 128: the rolling kernel for that width only (experiments)
-        if (only < 0) { const char *e = getenv("ERFNET_X3R_ONLY"); only = e ? atoi(e) : 0; }
-        if (g_sw_x3r.on() && !ld.stats && BM == 64 && dil > 0 && ld.s1[1] == 0 && ld.s1[2] == -ld.s1[0] &&
-            ld.lines_per_img % dil == 0 && (!only || only == NC)) {
-            if (NC == 128) line_x3r_kernel<128, 64><<<grid, 256, 0, st>>>(ld);
-            else line_x3r_kernel<64, 64><<<grid, 256, 0, st>>>(ld);
-            CHECK_LAUNCH("line_x3r_kernel");
-            return 0;
-        }
+    if (line_x3r_takes(ld, NC)) {
+        if (NC == 128) line_x3r_kernel<128, 64><<<grid, 256, 0, st>>>(ld);
+        else line_x3r_kernel<64, 64><<<grid, 256, 0, st>>>(ld);
+        CHECK_LAUNCH("line_x3r_kernel");
+        return 0;
     }
+    if (ld.epi1.bits_out || ld.epi1.mask_bits) return fail("line_x3_kernel: mask bits belong to the rolling kernel only");
 #define X3_LAUNCH(nc, bm)                                                                           \
     do {                                                                                            \
         if (ld.stats) line_x3_kernel<nc, bm, true><<<grid, 256, 0, st>>>(ld);                       \
@@ -1885,6 +1899,23 @@ int nb1d_chain_segment(int dt, const void *x, const erf_nb1d_block_t *blk, int n
         } else if (plan_igemm(P.d[3], ar, k[3])) return 1;
     }
     if (launch_pack(pk, 4 * nb, st)) return 1;             // one launch repacks the weights of the whole run
+    // ReLU masks as bits: out of the epilogues of the launches that end in the ReLU and run on the
+    // rolling kernel (not the paired launches, not a convolution followed by a BatchNorm pass)
+    for (int i = 0; i < nb; ++i) {
+        const erf_nb1d_block_t &B = blk[i];
+        Nb1dPlan &P = plan[i];
+        unsigned written = 0;
+        if (B.sign_bits) {
+            const bool own[4] = {!(i > 0 && plan[i - 1].pair_next), !P.pair12 && !P.tp1, !P.pair12,
+                                 !P.pair_next && !P.tp2};
+            for (int k = 0; k < 4; ++k) {
+                if (!B.sign_bits[k] || !own[k] || !P.d[k].epi.relu || !igemm_on_x3r(P.d[k])) continue;
+                P.d[k].epi.bits_out = B.sign_bits[k];
+                written |= 1u << k;
+            }
+        }
+        if (B.sign_bits_written) *B.sign_bits_written = written;
+    }
 
     for (int i = 0; i < nb; ++i) {
         const erf_nb1d_block_t &B = blk[i];
@@ -1955,6 +1986,7 @@ static int nb1d_forward_impl(int dt, const void *x, const float *const w[4], con
     erf_nb1d_block_t blk;
     for (int i = 0; i < 4; ++i) { blk.w[i] = w[i]; blk.b[i] = b[i]; }
     blk.bn1 = bn1; blk.bn2 = bn2; blk.drop_scale = drop_scale; blk.dil = dil; blk.y = y; blk.save = save;
+    blk.sign_bits = nullptr; blk.sign_bits_written = nullptr;
     return nb1d_chain_forward_impl(dt, x, &blk, 1, N, C, H, W, ws, ws_bytes, stream);
 }
 
@@ -2099,6 +2131,7 @@ int erf_conv_pair_forward_bf16(const void *x, const void *packed, const float *b
 
 static int nb1d_backward_impl(int dt, const void *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
                               const float *drop_scale, int dil, const void *y, const void *const save[5],
+                              const unsigned *const bits[4],
                               const void *gy, void *dx, float *const dw[4], float *const db[4],
                               float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, int flags,
                               void *ws, size_t ws_bytes, void *stream)
@@ -2151,6 +2184,15 @@ static int nb1d_backward_impl(int dt, const void *x, const float *const w[4], co
         pk[1] = two[0]; pk[0] = two[1];
     } else if (plan_igemm(d[1], ar, pk[1]) || plan_igemm(d[0], ar, pk[0])) return 1;
     if (launch_pack(pk, 4, st)) return 1;
+    if (bits) {     // masks given as bits serve the launches of the rolling kernel (t1, t2, t3, x -> d[1], d[2], d[3], d[0])
+        const int slot[4] = {3, 0, 1, 2};
+        const bool own[4] = {!pair10, !pair10, !pair32, !pair32};
+        for (int k = 0; k < 4; ++k) {
+            if (!bits[slot[k]] || !d[k].epi.mask || !own[k] || !igemm_on_x3r(d[k])) continue;
+            d[k].epi.mask_bits = bits[slot[k]];
+            d[k].epi.mask = nullptr; d[k].epi.mask_C = 0;
+        }
+    }
     // BatchNorm scratch first; the slabs of the four weight gradients follow it
     const size_t bn_bytes = 2 * bn_scratch_bytes(M, C);
     void *pbn = ar.take(bn_bytes);
@@ -2889,8 +2931,17 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
                       float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, int flags,
                       void *ws, size_t ws_bytes, void *stream)
 {
-    return nb1d_backward_impl(ERF_DT_F32, x, w, bn1, bn2, drop_scale, dil, y, (const void *const *)save, gy, dx, dw, db,
-                              dgamma, dbeta, N, C, H, W, flags, ws, ws_bytes, stream);
+    return nb1d_backward_impl(ERF_DT_F32, x, w, bn1, bn2, drop_scale, dil, y, (const void *const *)save, nullptr, gy, dx,
+                              dw, db, dgamma, dbeta, N, C, H, W, flags, ws, ws_bytes, stream);
+}
+int erf_nb1d_backward_bits(const float *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
+                           const float *drop_scale, int dil, const float *y, const float *const save[5],
+                           const unsigned *const sign_bits[4], const float *gy, float *dx, float *const dw[4],
+                           float *const db[4], float *const dgamma[2], float *const dbeta[2], int N, int C, int H,
+                           int W, int flags, void *ws, size_t ws_bytes, void *stream)
+{
+    return nb1d_backward_impl(ERF_DT_F32, x, w, bn1, bn2, drop_scale, dil, y, (const void *const *)save, sign_bits, gy,
+                              dx, dw, db, dgamma, dbeta, N, C, H, W, flags, ws, ws_bytes, stream);
 }
 int erf_nb1d_backward_bf16(const void *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
                            const float *drop_scale, int dil, const void *y, const void *const save[5],
@@ -2898,8 +2949,8 @@ int erf_nb1d_backward_bf16(const void *x, const float *const w[4], const erf_bn_
                            float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W, int flags,
                            void *ws, size_t ws_bytes, void *stream)
 {
-    return nb1d_backward_impl(ERF_DT_BF16, x, w, bn1, bn2, drop_scale, dil, y, save, gy, dx, dw, db, dgamma, dbeta, N, C,
-                              H, W, flags, ws, ws_bytes, stream);
+    return nb1d_backward_impl(ERF_DT_BF16, x, w, bn1, bn2, drop_scale, dil, y, save, nullptr, gy, dx, dw, db, dgamma,
+                              dbeta, N, C, H, W, flags, ws, ws_bytes, stream);
 }
 
 int erf_upsampler_forward(const float *x, const float *w, const float *b, const erf_bn_t *bn, float *y,

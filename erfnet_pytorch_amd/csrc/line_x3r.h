@@ -36,10 +36,10 @@ __device__ __forceinline__ unsigned x3r_opaque(unsigned v)
 }
 
 #ifndef X3R_PFA64
-#define X3R_PFA64 1
+#define X3R_PFA64 0
 #endif
 #ifndef X3R_PFA128
-#define X3R_PFA128 2
+#define X3R_PFA128 1
 #endif
 template <int NC, int BM>
 __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const LineDesc d)
@@ -319,10 +319,30 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
     // begin and has landed when the epilogue needs it; with both tensors the mask is read in the
     // epilogue.  PFA pixel tiles of a wave are covered (register budget).
     constexpr int PFA0 = NC == 64 ? X3R_PFA64 : X3R_PFA128, PFA = PFA0 < WM ? PFA0 : WM;
-    const bool has_res = d.epi1.res != nullptr, masked = d.epi1.mask != nullptr;        // wave-uniform
+    // (all wave-uniform) a bit tensor, when given, stands for the mask tensor
+    const bool has_res = d.epi1.res != nullptr, bits_in = d.epi1.mask_bits != nullptr, bits_out = d.epi1.bits_out != nullptr;
+    const bool masked = !bits_in && d.epi1.mask != nullptr;
+    const unsigned bbytes = (unsigned)((size_t)d.N * d.img_pixels * GC * 4);
+    const __amdgpu_buffer_rsrc_t rbi = make_rsrc(d.epi1.mask_bits, bbytes);
+    const __amdgpu_buffer_rsrc_t rbo = make_rsrc(d.epi1.bits_out, bbytes);
+    unsigned bo[WM], mbits[WM];         // this lane's word of a pixel tile (byte offset), the mask bits of the current line
+#pragma unroll
+    for (int a = 0; a < WM; ++a) {
+        const int px = (wp * WM + a) * 32 + l31;
+        bo[a] = (unsigned)(px * d.pstride * GC + cg) * 4u;
+        mbits[a] = 0u;
+    }
     const __amdgpu_buffer_rsrc_t rpf = make_rsrc(has_res ? d.epi1.res : d.epi1.mask, tbytes);
     f32x4 pf[PFA > 0 ? PFA : 1][4];
     auto prefetch = [&](unsigned soff, int len) __attribute__((always_inline)) {
+        if (bits_in) {          // (a pixel's words sit at 1/32 of its activations' byte offset)
+#pragma unroll
+            for (int a = 0; a < WM; ++a) {
+                const int px = (wp * WM + a) * 32 + (int)x3r_opaque((unsigned)l31);
+                const unsigned vo = px < len ? x3r_opaque(bo[a]) : ERF_OOB;
+                mbits[a] = __builtin_amdgcn_raw_buffer_load_b32(rbi, (int)vo, (int)(soff >> 5), 0);
+            }
+        }
         if (PFA == 0 || (!has_res && !masked)) return;
 #pragma unroll
         for (int a = 0; a < PFA; ++a) {
@@ -369,10 +389,33 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[a][4 * gq + e] = mm[gq][e] > 0.0f ? acc[a][4 * gq + e] : 0.0f;
             }
+            if (bits_in) {
+                // bit 8 gq + 4 h + e of the word belongs to this lane's element (gq, e)
+                const unsigned m = mbits[a] >> (4u * x3r_opaque((unsigned)h));
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // (a bit cast applied to a vector's element reads element 0: go through a scalar)
+                        const float v = acc[a][4 * gq + e];
+                        acc[a][4 * gq + e] = ((m >> (8 * gq + e)) & 1u) ? v : 0.0f;
+                    }
+            }
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const f32x4 v = f32x4{acc[a][4 * gq], acc[a][4 * gq + 1], acc[a][4 * gq + 2], acc[a][4 * gq + 3]};
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)vo, (int)(soff + 32u * gq), 0);
+            }
+            if (bits_out) {
+                unsigned wbits = 0u;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wbits |= (acc[a][4 * gq + e] > 0.0f ? 1u : 0u) << (8 * gq + e);
+                wbits <<= 4u * x3r_opaque((unsigned)h);
+                wbits |= (unsigned)__shfl_xor((int)wbits, 32);          // the other half of the 32 channels
+                const unsigned vw = (px < len && x3r_opaque((unsigned)h) == 0u) ? x3r_opaque(bo[a]) : ERF_OOB;
+                __builtin_amdgcn_raw_buffer_store_b32(wbits, rbo, (int)vw, (int)(soff >> 5), 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;

@@ -419,6 +419,18 @@ def nb1d(x, weights, biases, dilated, bn1=None, bn2=None, bn_mode=0, drop_scale=
                                    drop_scale, dilated, bn_mode, momentum, eps, tok), tok)
 
 
+# The ReLU masks of a run of blocks travel to its backward as bit tensors (sign_bits of
+# erf_nb1d_block_t) unless ERFNET_NO_SIGN_BITS=1 (A/B runs); results are bit-identical either way.
+_SIGN_BITS = os.environ.get("ERFNET_NO_SIGN_BITS", "0") in ("", "0")
+
+
+def set_sign_bits(enabled):
+    """Turn the bit-tensor ReLU masks of :func:`nb1d_chain` on or off; returns the previous setting."""
+    global _SIGN_BITS
+    prev, _SIGN_BITS = _SIGN_BITS, bool(enabled)
+    return prev
+
+
 class _Nb1dChain(torch.autograd.Function):
     """A run of non_bottleneck_1d blocks as one autograd node: the forward hands the whole run to
     erf_nb1d_chain_forward, the backward walks the blocks in reverse through erf_nb1d_backward and
@@ -472,17 +484,31 @@ class _Nb1dChain(torch.autograd.Function):
                 arr = _arr(save)
                 keep.append(arr)
                 B.save = C.cast(arr, C.POINTER(vp))
+            bits = None
+            if need and _SIGN_BITS and x.dtype == torch.float32 and c % 32 == 0:
+                # the ReLU masks of t1, t2, t3, y as bits (1/32 of an activation each): the library
+                # fills those it can and says which; the backward's masked launches read them
+                bits = torch.empty((4, n * h * wd * (c // 32)), dtype=torch.int32, device=x.device)
+                barr = (vp * 4)(*[bits[k].data_ptr() for k in range(4)])
+                flag = C.c_uint(0)
+                keep += [barr, flag]
+                B.sign_bits = C.cast(barr, C.POINTER(vp))
+                B.sign_bits_written = C.pointer(flag)
+                bits = (bits, flag)
             keep += [bn1, bn2, ws_, bs_, ds]
-            per_block.append((y, save, ws_, bn1, bn2, ds))
+            per_block.append((y, save, ws_, bn1, bn2, ds, bits))
         ws = _workspace(x, n * h * wd, c)
         with _dev_ctx(x):
             _lib.check(_fn("erf_nb1d_chain_forward", x)(_p(x), blocks, nb, n, c, h, wd, _p(ws), ws.numel(),
                                                         _stream(x)))
         if need:
             tensors = [x]
-            for y, save, ws_, bn1, bn2, ds in per_block:
+            ctx.bits_written = []
+            for y, save, ws_, bn1, bn2, ds, bits in per_block:
+                written = bits[1].value if bits is not None else 0
+                ctx.bits_written.append(written)
                 tensors += [y, *save, *ws_, bn1.gamma, bn2.gamma, bn1.save_mean, bn1.save_invstd,
-                            bn2.save_mean, bn2.save_invstd, ds]
+                            bn2.save_mean, bn2.save_invstd, ds, bits[0] if written else None]
             ctx.save_for_backward(*tensors)
             ctx.cfg = [(int(m["dil"]), m["mode"], m["momentum"], m["eps"]) for m in meta]
             ctx.params = flat
@@ -495,14 +521,18 @@ class _Nb1dChain(torch.autograd.Function):
         x0 = saved[0]
         n, c, h, wd = x0.shape
         nb = len(ctx.cfg)
-        per = 17            # tensors saved per block
+        per = 18            # tensors saved per block
         gy = _nhwc(gy, x0.dtype)
         last_flags = _bwd_flags(ctx, gy)
         grads = [None] * (nb * 12)
         ws = _workspace(x0, n * h * wd, c)
         for i in reversed(range(nb)):
-            (y, t1, p2, t2, t3, p4, w0, w1, w2, w3, g1, g2, sm1, si1, sm2, si2, ds) = saved[1 + i * per:1 + (i + 1) * per]
+            (y, t1, p2, t2, t3, p4, w0, w1, w2, w3, g1, g2, sm1, si1, sm2, si2, ds, bits) = saved[1 + i * per:1 + (i + 1) * per]
             x = saved[1 + (i - 1) * per] if i else x0
+            # mask bits of t1, t2, t3 (this block's) and of x (the previous block's y), where written
+            sb = [bits[k] if bits is not None and ctx.bits_written[i] >> k & 1 else None for k in range(3)]
+            xbits = saved[(i - 1) * per + per] if i else None
+            sb.append(xbits[3] if xbits is not None and ctx.bits_written[i - 1] >> 3 & 1 else None)
             dil, mode, momentum, eps = ctx.cfg[i]
             bn1 = _Bn(mode, g1, None, None, None, momentum, eps, False, saved=(sm1, si1))
             bn2 = _Bn(mode, g2, None, None, None, momentum, eps, False, saved=(sm2, si2))
@@ -523,10 +553,16 @@ class _Nb1dChain(torch.autograd.Function):
             if i > 0 or ctx.in_token is not None:
                 flags |= _lib.BWD_MASK_DX
             with _dev_ctx(x):
-                _lib.check(_fn("erf_nb1d_backward", x)(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
-                                                 dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
-                                                 _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
-                                                 flags, _p(ws), ws.numel(), _stream(x)))
+                if any(b is not None for b in sb):
+                    _lib.check(lib.erf_nb1d_backward_bits(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
+                                                          dil, _p(y), _arr([t1, p2, t2, t3, p4]), _arr(sb), _p(gy),
+                                                          _p(dx), _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c,
+                                                          h, wd, flags, _p(ws), ws.numel(), _stream(x)))
+                else:
+                    _lib.check(_fn("erf_nb1d_backward", x)(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
+                                                           dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
+                                                           _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
+                                                           flags, _p(ws), ws.numel(), _stream(x)))
             grads[i * 12:(i + 1) * 12] = _match_params(_deliver(tg), params)
             gy = dx
         return (_hand_over(ctx, gy), None, None, *grads)

@@ -49,8 +49,9 @@ typedef struct {
  * built with; a caller compiled against this header compares it with ERF_ABI_VERSION and refuses a
  * mismatch (struct layouts are part of the ABI: revision 101 added erf_bn_t::num_batches_tracked and
  * changed erf_nb1d_block_t's member types, 102 added ERF_OPT_X3_ROLL and the capture rule of
- * erf_cross_entropy_forward_static). */
-#define ERF_ABI_VERSION 102
+ * erf_cross_entropy_forward_static, 103 added erf_nb1d_block_t::sign_bits / sign_bits_written and
+ * erf_nb1d_backward_bits). */
+#define ERF_ABI_VERSION 103
 int erf_version(void);
 const char *erf_last_error(void);
 /* Number of kernel launches issued through this library by the calling process (tests use it to
@@ -152,6 +153,15 @@ typedef struct {
     int dil;
     void *y;                /* fp32 tensors for erf_nb1d_chain_forward, bf16 for the _bf16 variant */
     void *const *save;
+    /* The ReLU masks of the block for the backward pass, one bit per element instead of the
+     * activation itself (no counterpart in the reference, whose autograd keeps the activations):
+     * NULL, or 4 device buffers (any of them NULL) of N*H*W*C/32 words for t1, t2, t3 and y; word
+     * [pixel][c / 32] holds (value > 0) of channel c in bit c % 32.  The library fills the buffers
+     * it can fill for free (from the epilogue of the kernel that writes the tensor) and reports
+     * which in *sign_bits_written (host memory, bit k = buffer k; set when the call returns, not
+     * when the stream gets there).  The tensors themselves are written either way. */
+    unsigned *const *sign_bits;
+    unsigned *sign_bits_written;
 } erf_nb1d_block_t;
 int erf_nb1d_chain_forward(const float *x, const erf_nb1d_block_t *blocks, int nblocks, int N, int C,
                            int H, int W, void *ws, size_t ws_bytes, void *stream);
@@ -161,6 +171,17 @@ int erf_nb1d_backward(const float *x, const float *const w[4], const erf_bn_t *b
                       const float *const save[5], const float *gy, float *dx, float *const dw[4],
                       float *const db[4], float *const dgamma[2], float *const dbeta[2], int N,
                       int C, int H, int W, int flags, void *ws, size_t ws_bytes, void *stream);
+/* The same with the masks a forward call left in erf_nb1d_block_t::sign_bits: sign_bits[4] =
+ * the bit buffers of t1, t2, t3 and of x (= the y buffer of the block that produced x), each NULL
+ * when it was not written.  A data-gradient launch reads 1/32 of the bytes for its mask where the
+ * bits are given; save[] and x are still required (the weight gradients read them).  Results are
+ * bit-identical to erf_nb1d_backward. */
+int erf_nb1d_backward_bits(const float *x, const float *const w[4], const erf_bn_t *bn1,
+                           const erf_bn_t *bn2, const float *drop_scale, int dil, const float *y,
+                           const float *const save[5], const unsigned *const sign_bits[4],
+                           const float *gy, float *dx, float *const dw[4], float *const db[4],
+                           float *const dgamma[2], float *const dbeta[2], int N, int C, int H, int W,
+                           int flags, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- Two chained 1-D convolutions (train/erfnet_blocks.py:57-62 and 64-66: conv -> [relu] ->
  *      conv of a non_bottleneck_1d), C -> C channels, 3 taps each, as ONE launch ------------------

@@ -74,6 +74,42 @@ void run(int N, int H, int W, int axis, int dil, bool flip, bool relu, bool res,
     for (int i = 0; i < reps; ++i) line_x3r_kernel<NC, BM><<<grid, 256>>>(d);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms1, e0, e1));
     CK(hipDeviceSynchronize());
+    // the ReLU masks as bit tensors: the mask read from bits must give the very same output, and the
+    // bits written for the output must say (output > 0)
+    {
+        const int GCW = NC / 32;
+        std::vector<unsigned> hbits(P * GCW, 0u), hbo(P * GCW, 0u);
+        for (size_t px = 0; px < P; ++px)
+            for (int c = 0; c < NC; ++c)
+                if (hm[px * NC + c] > 0.0f) hbits[px * GCW + c / 32] |= 1u << (c % 32);
+        unsigned *bi, *bo_;
+        float *y2;
+        CK(hipMalloc(&bi, hbits.size() * 4)); CK(hipMalloc(&bo_, hbits.size() * 4)); CK(hipMalloc(&y2, E * 4));
+        CK(hipMemcpy(bi, hbits.data(), hbits.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemset(bo_, 0xff, hbits.size() * 4)); CK(hipMemset(y2, 0xff, E * 4));
+        LineDesc d2 = d;
+        d2.out = (bf16_t *)y2;
+        d2.epi1.bits_out = bo_;
+        if (mask) d2.epi1.mask_bits = bi;
+        line_x3r_kernel<NC, BM><<<grid, 256>>>(d2);
+        CK(hipDeviceSynchronize());
+        std::vector<float> h2(E), h1b(E);
+        CK(hipMemcpy(h2.data(), y2, E * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1b.data(), y1, E * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hbo.data(), bo_, hbo.size() * 4, hipMemcpyDeviceToHost));
+        size_t badv = 0, badb = 0;
+        for (size_t i = 0; i < E; ++i) if (memcmp(&h2[i], &h1b[i], 4)) {
+            if (badv < 6) { unsigned u; memcpy(&u, &h2[i], 4); printf("  elem %zu (pixel %zu c %zu): mask %g fp32-mask run %g bits run %g (%08x) word %08x\n", i, i / NC, i % NC, hm[i], h1b[i], h2[i], u, hbits[(i / NC) * GCW + (i % NC) / 32]); }
+            ++badv;
+        }
+        for (size_t px = 0; px < P; ++px)
+            for (int gw = 0; gw < GCW; ++gw) {
+                unsigned want = 0u;
+                for (int c = 0; c < 32; ++c) if (h2[px * NC + gw * 32 + c] > 0.0f) want |= 1u << c;
+                if (want != hbo[px * GCW + gw]) ++badb;
+            }
+        if (badv || badb) { ++g_fail; printf("FAIL bits: %zu values differ with the mask read from bits, %zu bit words wrong\n", badv, badb); }
+        hipFree(bi); hipFree(bo_); hipFree(y2);
+    }
     std::vector<float> h0(E), h1(E);
     CK(hipMemcpy(h0.data(), y0, E * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), y1, E * 4, hipMemcpyDeviceToHost));
     double maxd = 0, scale = 0;

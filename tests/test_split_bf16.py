@@ -161,3 +161,77 @@ def test_split_kernels_on_non_finite_and_tiny_inputs():
         assert torch.isfinite(y).all()
         assert (y.double() - r).abs().max() <= tol * r.abs().max(), e
     assert torch.equal(run(torch.zeros_like(x)), torch.zeros(N, C_, H, W))
+
+
+def _pack_sign_bits(t):
+    """(t > 0) of an [N,C,H,W] tensor as the library lays it out: word [pixel][c / 32], bit c % 32."""
+    n, c, h, w = t.shape
+    b = (t.permute(0, 2, 3, 1).reshape(-1, c // 32, 32) > 0).to(torch.int64)
+    return (b << torch.arange(32, device=t.device)).sum(dim=2).reshape(-1)
+
+
+@pytest.mark.parametrize("C_,N,H,W,dils,bn_mode", [(64, 2, 40, 72, (1, 2, 4), 0), (128, 1, 33, 64, (2, 16, 1), 0),
+                                                   (64, 1, 24, 100, (1, 8), 2), (128, 2, 20, 24, (4, 2), 2), (128, 1, 48, 40, (4, 2), 2),
+                                                   (64, 1, 20, 30, (3, 1), 0)])
+def test_relu_masks_as_bits(split_on, C_, N, H, W, dils, bn_mode):
+    """A run of blocks keeps its ReLU masks as bit tensors (erf_nb1d_block_t::sign_bits) and hands them to
+    erf_nb1d_backward_bits: the bits written equal (activation > 0), every launch that can write or
+    read them does (without BatchNorm all four tensors of a block when the lines divide by the
+    dilation, with it t1 and t3), and every gradient equals the run with the masks read from the
+    activations bit for bit."""
+    from erfnet_pytorch_amd import functional as hipf
+    g = torch.Generator(device="cpu").manual_seed(C_ + H)
+    x = torch.randn(N, C_, H, W, generator=g).clamp_(min=0).to(DEV).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, C_, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    blocks = []
+    for d in dils:
+        ws = [(torch.randn(C_, C_, *k, generator=g) * (0.5 / C_ ** 0.5)).to(DEV).requires_grad_(True)
+              for k in ((3, 1), (1, 3), (3, 1), (1, 3))]
+        bs = [(torch.randn(C_, generator=g) * 0.1).to(DEV).requires_grad_(True) for _ in range(4)]
+        b = dict(weights=ws, biases=bs, dilated=d)
+        if bn_mode:
+            b["bn_mode"] = bn_mode
+            for key in ("bn1", "bn2"):
+                b[key] = ((torch.rand(C_, generator=g) + 0.5).to(DEV).requires_grad_(True),
+                          (torch.randn(C_, generator=g) * 0.1).to(DEV).requires_grad_(True),
+                          torch.zeros(C_, device=DEV), torch.ones(C_, device=DEV))
+        blocks.append(b)
+    leaves = [q for b in blocks for q in b["weights"] + b["biases"] +
+              ([b["bn1"][0], b["bn1"][1], b["bn2"][0], b["bn2"][1]] if bn_mode else [])]
+    res = []
+    for on in (False, True):
+        prev = hipf.set_sign_bits(on)
+        try:
+            for q in leaves:
+                q.grad = None
+            xx = x.clone().requires_grad_(True)
+            y = hipf.nb1d_chain(xx, blocks)
+            node = y.grad_fn
+            while node is not None and not hasattr(node, "bits_written"):
+                node = node.next_functions[0][0] if node.next_functions else None
+            assert node is not None
+            if on:
+                per = 18
+                saved = node.saved_tensors
+                for i, d in enumerate(dils):
+                    # a convolution along H takes the image rows as lines (H of them, W pixels long), one
+                    # along W the columns; the rolling kernel wants 64-pixel tiles (128 channels: lines
+                    # longer than 32 pixels) and line counts that divide by the dilation
+                    geo = [(H, W, 1), (W, H, 1), (H, W, d), (W, H, d)]
+                    fits = [(C_ == 64 or length > 32) and lines % dl == 0 for lines, length, dl in geo]
+                    want = sum(1 << k for k in range(4) if fits[k] and not (bn_mode and k in (1, 3)))
+                    assert node.bits_written[i] == want, (i, node.bits_written)
+                    blk = saved[1 + i * per:1 + (i + 1) * per]
+                    acts = {0: blk[1], 1: blk[3], 2: blk[4], 3: blk[0]}        # t1, t2, t3, y
+                    for k in range(4):
+                        if node.bits_written[i] >> k & 1:
+                            got = blk[17][k].to(torch.int64) & 0xFFFFFFFF
+                            assert torch.equal(got, _pack_sign_bits(acts[k])), (i, k)
+            else:
+                assert not any(node.bits_written)
+            y.backward(gy)
+            res.append([y.detach(), xx.grad] + [q.grad.clone() for q in leaves])
+        finally:
+            hipf.set_sign_bits(prev)
+    for i, (u, v) in enumerate(zip(*res)):
+        assert torch.equal(u, v), f"tensor {i}"
