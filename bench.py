@@ -228,17 +228,20 @@ def dominant_kernel_roofline(device, batch):
     k128 = line_conv_roofline(device, batch, 128, 8, 2)
     s64, s128 = k64["share_of_step"] or 0.0, k128["share_of_step"] or 0.0
     dom, other = (k64, k128) if s64 >= s128 else (k128, k64)
-    traffic, source = None, None
+    # HBM bytes per launch from the committed PMC passes (same launch geometry), per width
     tj = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
-    if os.path.exists(tj):
-        try:
-            rec = json.load(open(tj))
-            if rec.get("kernel", "").replace(" ", "") == dom["kernel"].split(" (")[0].replace(" ", ""):
-                traffic = rec.get("hbm_bytes_per_launch")
-                source = "profiles/dominant_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
-                         "not measured in this run)"
-        except Exception:
-            traffic = None
+    source = None
+    try:
+        recs = json.load(open(tj)).get("kernels", {})
+    except Exception:
+        recs = {}
+    for k in (k64, k128):
+        rec = recs.get(k["kernel"].split(" (")[0])
+        k["hbm_bytes_per_launch_pmc"] = rec.get("hbm_bytes_per_launch") if rec else None
+    traffic = dom["hbm_bytes_per_launch_pmc"]
+    if traffic is not None:
+        source = "profiles/dominant_kernel_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, " \
+                 "not measured in this run)"
     hbm_bound = dom["hbm_floor_us"] >= dom["mfma_floor_us"]
     out = {"bound": "hbm" if hbm_bound else "mfma",
            "achieved": dom["hbm_gbs"] if hbm_bound else dom["tflops"],
