@@ -132,7 +132,7 @@ _PROTOS = {
 
 # bf16 variants: same argument lists (activation pointers are bf16 tensors, parameters stay fp32)
 for _n in ("erf_downsampler_forward", "erf_downsampler_backward", "erf_nb1d_forward", "erf_nb1d_chain_forward",
-           "erf_nb1d_backward", "erf_upsampler_forward", "erf_upsampler_backward", "erf_outconv_argmax",
+           "erf_nb1d_backward", "erf_nb1d_backward_bits", "erf_upsampler_forward", "erf_upsampler_backward", "erf_outconv_argmax",
            "erf_outconv_backward", "erf_outconv_ce_backward", "erf_outconv_ce_forward", "erf_conv2d_forward", "erf_conv2d_backward", "erf_conv_pair_pack",
            "erf_conv_pair_forward"):
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]

@@ -208,17 +208,25 @@ int launch_line_pack(const LinePackDesc *pks, int n, hipStream_t st)
     return 0;
 }
 
+// Pairs whose blocks see at least two tiles take the eight-wave kernel (conv_a of tile k+1 beside
+// conv_b of tile k); ERFNET_NO_LINE2=1 keeps them on the four-wave one (experiments, A/B tests).
+bool line2_takes(const LineDesc &ld, int NC, int BM, bool pair)
+{
+    static int no_line2 = -1;
+    if (no_line2 < 0) { const char *e = getenv("ERFNET_NO_LINE2"); no_line2 = (e && atoi(e)) ? 1 : 0; }
+    const int ntiles = ld.nlines * ld.segs;
+    const int cus = cu_count();
+    const int grid = ntiles < cus ? ntiles : cus;
+    if (!pair || no_line2 || !g_line2.load(std::memory_order_relaxed) || ld.segs != 1 || ntiles < 2 * grid) return false;
+    return (NC == 128 && (BM == 32 || BM == 64)) || (NC == 64 && (BM == 64 || BM == 128));
+}
 int run_line(const LineDesc &ld, int NC, int BM, bool pair, hipStream_t st)
 {
     const int ntiles = ld.nlines * ld.segs;
     if (ntiles <= 0) return 0;
     const int cus = cu_count();
     const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-    // Pairs whose blocks see at least two tiles take the eight-wave kernel (conv_a of tile k+1 beside
-    // conv_b of tile k); ERFNET_NO_LINE2=1 keeps them on the four-wave one (experiments, A/B tests).
-    static int no_line2 = -1;
-    if (no_line2 < 0) { const char *e = getenv("ERFNET_NO_LINE2"); no_line2 = (e && atoi(e)) ? 1 : 0; }
-    if (pair && !no_line2 && g_line2.load(std::memory_order_relaxed) && ld.segs == 1 && ntiles >= 2 * (int)grid) {
+    if (line2_takes(ld, NC, BM, pair)) {
 #define LINE2_CASE(nc, bm)                                                                          \
         if (NC == nc && BM == bm) {                                                                 \
             line2_bf16_kernel<nc, bm><<<grid, 512, 0, st>>>(ld);                                    \
@@ -228,6 +236,8 @@ int run_line(const LineDesc &ld, int NC, int BM, bool pair, hipStream_t st)
         LINE2_CASE(128, 32) LINE2_CASE(128, 64) LINE2_CASE(64, 64) LINE2_CASE(64, 128)
 #undef LINE2_CASE
     }
+    if (ld.epi1.bits_out || ld.epi1.mask_bits || ld.epi2.bits_out || ld.epi2.mask_bits)
+        return fail("bf16 line kernel: mask bits belong to the eight-wave pair kernel only");
 #define LINE_CASE(nc, bm)                                                                           \
     if (NC == nc && BM == bm) {                                                                     \
         if (pair) line_bf16_kernel<nc, bm, true><<<grid, 256, 0, st>>>(ld);                        \
@@ -1916,6 +1926,25 @@ int nb1d_chain_segment(int dt, const void *x, const erf_nb1d_block_t *blk, int n
         }
         if (B.sign_bits_written) *B.sign_bits_written = written;
     }
+    // bf16 tensors: the eight-wave pair kernel writes the bits of both of its outputs (conv1x3_1 +
+    // conv3x1_2 -> t2, t3; conv1x3_2 + the next block's conv3x1_1 -> y, the next block's t1)
+    for (int i = 0; dt && i < nb; ++i) {
+        const erf_nb1d_block_t &B = blk[i];
+        Nb1dPlan &P = plan[i];
+        auto give = [&](Epilogue &e, const erf_nb1d_block_t &owner, int k) {
+            if (!owner.sign_bits || !owner.sign_bits[k] || !owner.sign_bits_written || !e.relu) return;
+            e.bits_out = owner.sign_bits[k];
+            *owner.sign_bits_written |= 1u << k;
+        };
+        if (P.pair12 && !P.pd12.p16_on && B.save && line2_takes(P.pd12.ld, C, P.pair12, true)) {
+            give(P.pd12.ld.epi1, B, 1);
+            give(P.pd12.ld.epi2, B, 2);
+        }
+        if (P.pair_next && !P.pdn.p16_on && line2_takes(P.pdn.ld, C, P.pair_next, true)) {
+            give(P.pdn.ld.epi1, B, 3);
+            give(P.pdn.ld.epi2, blk[i + 1], 0);
+        }
+    }
 
     for (int i = 0; i < nb; ++i) {
         const erf_nb1d_block_t &B = blk[i];
@@ -2192,6 +2221,15 @@ static int nb1d_backward_impl(int dt, const void *x, const float *const w[4], co
             d[k].epi.mask_bits = bits[slot[k]];
             d[k].epi.mask = nullptr; d[k].epi.mask_C = 0;
         }
+    }
+    if (bits && dt) {   // bf16: the eight-wave pair kernel reads either form, each of its two masks on its own
+        auto take = [&](Epilogue &e, int k) {
+            if (!bits[k] || !e.mask) return;
+            e.mask_bits = bits[k];
+            e.mask = nullptr; e.mask_C = 0;
+        };
+        if (pair32 && !pd32.p16_on && line2_takes(pd32.ld, C, pair32, true)) { take(pd32.ld.epi1, 2); take(pd32.ld.epi2, 1); }
+        if (pair10 && !pd10.p16_on && line2_takes(pd10.ld, C, pair10, true)) { take(pd10.ld.epi1, 0); take(pd10.ld.epi2, 3); }
     }
     // BatchNorm scratch first; the slabs of the four weight gradients follow it
     const size_t bn_bytes = 2 * bn_scratch_bytes(M, C);
@@ -2942,6 +2980,15 @@ int erf_nb1d_backward_bits(const float *x, const float *const w[4], const erf_bn
 {
     return nb1d_backward_impl(ERF_DT_F32, x, w, bn1, bn2, drop_scale, dil, y, (const void *const *)save, sign_bits, gy,
                               dx, dw, db, dgamma, dbeta, N, C, H, W, flags, ws, ws_bytes, stream);
+}
+int erf_nb1d_backward_bits_bf16(const void *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
+                                const float *drop_scale, int dil, const void *y, const void *const save[5],
+                                const unsigned *const sign_bits[4], const void *gy, void *dx, float *const dw[4],
+                                float *const db[4], float *const dgamma[2], float *const dbeta[2], int N, int C, int H,
+                                int W, int flags, void *ws, size_t ws_bytes, void *stream)
+{
+    return nb1d_backward_impl(ERF_DT_BF16, x, w, bn1, bn2, drop_scale, dil, y, save, sign_bits, gy, dx, dw, db, dgamma,
+                              dbeta, N, C, H, W, flags, ws, ws_bytes, stream);
 }
 int erf_nb1d_backward_bf16(const void *x, const float *const w[4], const erf_bn_t *bn1, const erf_bn_t *bn2,
                            const float *drop_scale, int dil, const void *y, const void *const save[5],

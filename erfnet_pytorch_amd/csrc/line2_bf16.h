@@ -127,13 +127,30 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // coalesced pass of a role over a finished LDS tile: [mask by a global tensor, kept in the tile] -> [global store]
-    auto sweep_tile = [&](int lds_off, const bf16_t *mk, bf16_t *dst, bool keep, const Geo &g) __attribute__((always_inline)) {
+    // coalesced pass of a role over a finished LDS tile: [mask by a global tensor or by its bit
+    // tensor, kept in the tile] -> [global store] -> [the stored values' "> 0" bits].  A thread holds 8
+    // channels = one byte of a pixel's mask words; the four lanes of a quad hold the four bytes of a word.
+    // The mask words of a tile are requested early (fetch_bits: a few registers, a load latency the
+    // pass would otherwise wait out) and handed in.
+    auto fetch_bits = [&](const unsigned *mkb, unsigned (&mw)[PASSES], const Geo &g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            const int slot = p * 256 + ltid;
+            const int r = slot / CPR, pc = slot % CPR;
+            const int c = pc ^ line_swz<NC>(r);
+            const int rr = r < g.len ? r : g.len - 1;
+            const unsigned pix = g.base + (unsigned)(rr * d.pstride);
+            mw[p] = mkb[pix * (unsigned)(NC / 32) + (unsigned)(c >> 2)];
+        }
+    };
+    auto sweep_tile = [&](int lds_off, const bf16_t *mk, const unsigned (&mw)[PASSES], bool bits_in, bf16_t *dst,
+                          unsigned *ob, bool keep, const Geo &g) __attribute__((always_inline)) {
         constexpr int B = PASSES % 4 == 0 ? 4 : (PASSES % 2 == 0 ? 2 : 1);
 #pragma unroll
         for (int p0 = 0; p0 < PASSES; p0 += B) {
             u32x4 v[B], m[B];
             size_t off[B];
+            unsigned wix[B], csh[B];
             bool live[B];
 #pragma unroll
             for (int i = 0; i < B; ++i) {
@@ -142,7 +159,10 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
                 const int c = pc ^ line_swz<NC>(r);
                 live[i] = r < g.len;
                 const int rr = live[i] ? r : g.len - 1;
-                off[i] = (size_t)(g.base + (unsigned)(rr * d.pstride)) * NC + c * 8;
+                const unsigned pix = g.base + (unsigned)(rr * d.pstride);
+                off[i] = (size_t)pix * NC + c * 8;
+                wix[i] = pix * (unsigned)(NC / 32) + (unsigned)(c >> 2);
+                csh[i] = (unsigned)(c & 3) * 8u;
                 v[i] = *reinterpret_cast<const u32x4 *>(lds + lds_off + slot * 16);
             }
             if (mk) {
@@ -150,15 +170,27 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
                 for (int i = 0; i < B; ++i) m[i] = *reinterpret_cast<const u32x4 *>(mk + off[i]);
 #pragma unroll
                 for (int i = 0; i < B; ++i) v[i] = mask_bf16x8(v[i], m[i]);
-                if (keep) {
+            } else if (bits_in) {
 #pragma unroll
-                    for (int i = 0; i < B; ++i) *reinterpret_cast<u32x4 *>(lds + lds_off + ((p0 + i) * 256 + ltid) * 16) = v[i];
-                }
+                for (int i = 0; i < B; ++i) v[i] = mask_bits_bf16x8(v[i], mw[p0 + i] >> csh[i]);
+            }
+            if ((mk || bits_in) && keep) {
+#pragma unroll
+                for (int i = 0; i < B; ++i) *reinterpret_cast<u32x4 *>(lds + lds_off + ((p0 + i) * 256 + ltid) * 16) = v[i];
             }
             if (dst) {
 #pragma unroll
                 for (int i = 0; i < B; ++i)
                     if (live[i]) *reinterpret_cast<u32x4 *>(dst + off[i]) = v[i];
+            }
+            if (ob) {
+#pragma unroll
+                for (int i = 0; i < B; ++i) {
+                    int w = (int)(sign_bits_bf16x8(v[i]) << csh[i]);
+                    w |= __builtin_amdgcn_mov_dpp(w, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+                    w |= __builtin_amdgcn_mov_dpp(w, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+                    if (live[i] && (ltid & 3) == 0) ob[wix[i]] = (unsigned)w;
+                }
             }
         }
     };
@@ -225,6 +257,9 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
     if (role_a) {
         // ================================================================= role A: conv_a, tile by tile
         bf16x8 w1[3][KS];
+        const bf16_t *mk1 = (const bf16_t *)d.epi1.mask;
+        const unsigned *mkb1 = mk1 ? nullptr : d.epi1.mask_bits;
+        unsigned mw[PASSES] = {};
         int seq = 0;
         Geo g = geo(b0);
         {
@@ -248,6 +283,8 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
                 const bool tv = tap_valid(g, t);            // wave-uniform
                 if (tv) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 lds_barrier();                              // X1..X3
+                // (behind the tile's last wait for operand tiles: the words land during the last tap's MFMAs)
+                if (t == 2 && mkb1) fetch_bits(mkb1, mw, g);
                 if (!tv) continue;
                 int nt = t + 1;
                 while (nt < 3 && !tap_valid(g, nt)) ++nt;
@@ -274,8 +311,8 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
             store_acc(d.epi1, cst, cst + NC, res_first, true, OFF_RESA, mid_off, g);
             clear_acc();
             lds_barrier();                                  // X4
-            const bf16_t *mk1 = (const bf16_t *)d.epi1.mask;
-            if (d.mid || mk1) sweep_tile(mid_off, mk1, d.mid, true, g);
+            if (d.mid || mk1 || mkb1)
+                sweep_tile(mid_off, mk1, mw, mkb1 != nullptr, d.mid, d.mid ? d.epi1.bits_out : nullptr, true, g);
             lds_barrier();                                  // X5
             g = gn;
         }
@@ -285,6 +322,9 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
     } else {
         // ================================================================= role B: conv_b + output, one tile behind
         bf16x8 w2[3][KS];
+        const bf16_t *mk2 = (const bf16_t *)d.epi2.mask;
+        const unsigned *mkb2 = mk2 ? nullptr : d.epi2.mask_bits;
+        unsigned mw[PASSES] = {};
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -301,6 +341,7 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
             Geo gn = g;
             if (more) gn = geo(b0 + (k + 1) * nblk);
             const int mid_off = OFF_MID + (k & 1) * MIDSZ;
+            if (mkb2) fetch_bits(mkb2, mw, g);              // (land during this tile's MFMAs)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int sft = d.s2[t];
@@ -320,7 +361,7 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
             store_acc(d.epi2, cst + 2 * NC, cst + 3 * NC, res_last, false, OFF_RES, OFF_RES, g);
             clear_acc();
             lds_barrier();                                  // X2
-            sweep_tile(OFF_RES, (const bf16_t *)d.epi2.mask, d.out, false, g);
+            sweep_tile(OFF_RES, mk2, mw, mkb2 != nullptr, d.out, d.epi2.bits_out, false, g);
             lds_barrier();                                  // X3: the RES tile may be refilled
             if (more && res_last) issue_tile((const bf16_t *)d.epi2.res, gn.base, gn.len, OFF_RES);
             lds_barrier();                                  // X4

@@ -96,6 +96,36 @@ __device__ __forceinline__ void lds_dma16(const void *gsrc, unsigned lds_byte_ad
 }
 
 // bf16 patterns: zero the elements of v whose mask element is not > 0
+// The same with the mask given as 8 bits (bit j = keep element j; higher bits ignored), and the bits of
+// a vector of ReLU outputs (no element negative: "> 0" is "not zero" on the bit pattern).  The ReLU
+// masks travel as bit tensors, word [pixel][c / 32], bit c % 32.  Packed 16-bit arithmetic: a dozen
+// instructions per 8 elements either way.
+__device__ __forceinline__ u32x4 mask_bits_bf16x8(u32x4 v, unsigned bits)
+{
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    bits &= 0xffu;
+    const unsigned s = bits | (bits << 15);         // bit 2e -> bit 2e, bit 2e + 1 -> bit 2e + 16
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const u16x2 one = __builtin_bit_cast(u16x2, (s >> (2 * e)) & 0x00010001u);
+        const u16x2 keep = u16x2{0, 0} - one;       // 0xffff where the bit is set
+        o[e] = v[e] & __builtin_bit_cast(unsigned, keep);
+    }
+    return o;
+}
+__device__ __forceinline__ unsigned sign_bits_bf16x8(u32x4 v)
+{
+    unsigned b = 0u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned nz;                    // min(x, 1) on both halves (the compiler would expand it into compares)
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(v[e]), "s"(0x00010001u));
+        b |= nz << (2 * e);             // bits 2e and 2e + 16
+    }
+    return (b | (b >> 15)) & 0xffu;
+}
+
 __device__ __forceinline__ u32x4 mask_bf16x8(u32x4 v, u32x4 m)
 {
     u32x4 o;

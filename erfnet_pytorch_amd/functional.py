@@ -485,7 +485,7 @@ class _Nb1dChain(torch.autograd.Function):
                 keep.append(arr)
                 B.save = C.cast(arr, C.POINTER(vp))
             bits = None
-            if need and _SIGN_BITS and x.dtype == torch.float32 and c % 32 == 0:
+            if need and _SIGN_BITS and c % 32 == 0:
                 # the ReLU masks of t1, t2, t3, y as bits (1/32 of an activation each): the library
                 # fills those it can and says which; the backward's masked launches read them
                 bits = torch.empty((4, n * h * wd * (c // 32)), dtype=torch.int32, device=x.device)
@@ -554,7 +554,7 @@ class _Nb1dChain(torch.autograd.Function):
                 flags |= _lib.BWD_MASK_DX
             with _dev_ctx(x):
                 if any(b is not None for b in sb):
-                    _lib.check(lib.erf_nb1d_backward_bits(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
+                    _lib.check(_fn("erf_nb1d_backward_bits", x)(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
                                                           dil, _p(y), _arr([t1, p2, t2, t3, p4]), _arr(sb), _p(gy),
                                                           _p(dx), _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c,
                                                           h, wd, flags, _p(ws), ws.numel(), _stream(x)))

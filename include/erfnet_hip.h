@@ -401,6 +401,12 @@ int erf_nb1d_backward_bf16(const void *x, const float *const w[4], const erf_bn_
                            const void *const save[5], const void *gy, void *dx, float *const dw[4],
                            float *const db[4], float *const dgamma[2], float *const dbeta[2], int N,
                            int C, int H, int W, int flags, void *ws, size_t ws_bytes, void *stream);
+int erf_nb1d_backward_bits_bf16(const void *x, const float *const w[4], const erf_bn_t *bn1,
+                                const erf_bn_t *bn2, const float *drop_scale, int dil, const void *y,
+                                const void *const save[5], const unsigned *const sign_bits[4],
+                                const void *gy, void *dx, float *const dw[4], float *const db[4],
+                                float *const dgamma[2], float *const dbeta[2], int N, int C, int H,
+                                int W, int flags, void *ws, size_t ws_bytes, void *stream);
 /* packed: 2*3*C*C bf16 (MFMA weight fragments).  w_second may be NULL and dil_second 0: a single
  * convolution, y = act(conv_first(x) + b_first [+ residual]).  Lines longer than a tile (C = 128: 128
  * pixels, C = 64: 256) are accepted for a single convolution only. */

@@ -170,19 +170,30 @@ def _pack_sign_bits(t):
     return (b << torch.arange(32, device=t.device)).sum(dim=2).reshape(-1)
 
 
-@pytest.mark.parametrize("C_,N,H,W,dils,bn_mode", [(64, 2, 40, 72, (1, 2, 4), 0), (128, 1, 33, 64, (2, 16, 1), 0),
-                                                   (64, 1, 24, 100, (1, 8), 2), (128, 2, 20, 24, (4, 2), 2), (128, 1, 48, 40, (4, 2), 2),
-                                                   (64, 1, 20, 30, (3, 1), 0)])
-def test_relu_masks_as_bits(split_on, C_, N, H, W, dils, bn_mode):
-    """A run of blocks keeps its ReLU masks as bit tensors (erf_nb1d_block_t::sign_bits) and hands them to
-    erf_nb1d_backward_bits: the bits written equal (activation > 0), every launch that can write or
-    read them does (without BatchNorm all four tensors of a block when the lines divide by the
-    dilation, with it t1 and t3), and every gradient equals the run with the masks read from the
-    activations bit for bit."""
+def _expected_bits_fp32(C_, H, W, dils, bn_mode):
+    """Rolling kernel: a convolution along H takes the image rows as lines (H of them, W pixels long),
+    one along W the columns; it wants 64-pixel tiles (128 channels: lines longer than 32 pixels) and
+    line counts that divide by the dilation.  Behind a BatchNorm pass the ReLU is not the convolution's."""
+    out = []
+    for d in dils:
+        geo = [(H, W, 1), (W, H, 1), (H, W, d), (W, H, d)]
+        fits = [(C_ == 64 or length > 32) and lines % dl == 0 for lines, length, dl in geo]
+        out.append(sum(1 << k for k in range(4) if fits[k] and not (bn_mode and k in (1, 3))))
+    return out
+
+
+def _expected_bits_bf16(C_, H, W, dils, bn_mode):
+    """Eight-wave pair kernel: conv1x3_1 + conv3x1_2 write t2 and t3, conv1x3_2 + the next block's
+    conv3x1_1 write y and that block's t1 (no BatchNorm, at least two columns per block of the grid)."""
+    nb = len(dils)
+    return [6 | (8 if i + 1 < nb else 0) | (1 if i > 0 else 0) for i in range(nb)]
+
+
+def _run_bits_case(dtype, C_, N, H, W, dils, bn_mode, expected):
     from erfnet_pytorch_amd import functional as hipf
     g = torch.Generator(device="cpu").manual_seed(C_ + H)
-    x = torch.randn(N, C_, H, W, generator=g).clamp_(min=0).to(DEV).contiguous(memory_format=torch.channels_last)
-    gy = torch.randn(N, C_, H, W, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    x = torch.randn(N, C_, H, W, generator=g).clamp_(min=0).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(N, C_, H, W, generator=g).to(DEV).to(dtype).contiguous(memory_format=torch.channels_last)
     blocks = []
     for d in dils:
         ws = [(torch.randn(C_, C_, *k, generator=g) * (0.5 / C_ ** 0.5)).to(DEV).requires_grad_(True)
@@ -213,14 +224,8 @@ def test_relu_masks_as_bits(split_on, C_, N, H, W, dils, bn_mode):
             if on:
                 per = 18
                 saved = node.saved_tensors
-                for i, d in enumerate(dils):
-                    # a convolution along H takes the image rows as lines (H of them, W pixels long), one
-                    # along W the columns; the rolling kernel wants 64-pixel tiles (128 channels: lines
-                    # longer than 32 pixels) and line counts that divide by the dilation
-                    geo = [(H, W, 1), (W, H, 1), (H, W, d), (W, H, d)]
-                    fits = [(C_ == 64 or length > 32) and lines % dl == 0 for lines, length, dl in geo]
-                    want = sum(1 << k for k in range(4) if fits[k] and not (bn_mode and k in (1, 3)))
-                    assert node.bits_written[i] == want, (i, node.bits_written)
+                assert list(node.bits_written) == expected, (node.bits_written, expected)
+                for i in range(len(dils)):
                     blk = saved[1 + i * per:1 + (i + 1) * per]
                     acts = {0: blk[1], 1: blk[3], 2: blk[4], 3: blk[0]}        # t1, t2, t3, y
                     for k in range(4):
@@ -235,3 +240,23 @@ def test_relu_masks_as_bits(split_on, C_, N, H, W, dils, bn_mode):
             hipf.set_sign_bits(prev)
     for i, (u, v) in enumerate(zip(*res)):
         assert torch.equal(u, v), f"tensor {i}"
+
+
+@pytest.mark.parametrize("C_,N,H,W,dils,bn_mode", [(64, 2, 40, 72, (1, 2, 4), 0), (128, 1, 33, 64, (2, 16, 1), 0),
+                                                   (64, 1, 24, 100, (1, 8), 2), (128, 2, 20, 24, (4, 2), 2),
+                                                   (128, 1, 48, 40, (4, 2), 2), (64, 1, 20, 30, (3, 1), 0)])
+def test_relu_masks_as_bits(split_on, C_, N, H, W, dils, bn_mode):
+    """A run of blocks keeps its ReLU masks as bit tensors (erf_nb1d_block_t::sign_bits) and hands them to
+    erf_nb1d_backward_bits: the bits written equal (activation > 0), every launch that can write or
+    read them does (without BatchNorm all four tensors of a block when the lines divide by the
+    dilation, with it t1 and t3), and every gradient equals the run with the masks read from the
+    activations bit for bit."""
+    _run_bits_case(torch.float32, C_, N, H, W, dils, bn_mode, _expected_bits_fp32(C_, H, W, dils, bn_mode))
+
+
+@pytest.mark.parametrize("C_,N,H,W,dils", [(64, 4, 32, 128, (1, 2, 4)), (128, 4, 24, 128, (2, 4)), (64, 5, 100, 104, (8,)),
+                                           (128, 9, 64, 60, (16, 1, 2, 3))])
+def test_relu_masks_as_bits_bf16(C_, N, H, W, dils):
+    """The same on bf16 tensors, where the paired launches write and read the bits (ragged tiles and
+    single-block runs included)."""
+    _run_bits_case(torch.bfloat16, C_, N, H, W, dils, 0, _expected_bits_bf16(C_, H, W, dils, 0))
