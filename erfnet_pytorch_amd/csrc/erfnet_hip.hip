@@ -633,6 +633,26 @@ int run_igemm_t(const IgemmDesc &d, hipStream_t st)
                 return 0;
             }
         }
+        if constexpr (std::is_same<T, float>::value) {
+            // rows variant (fp32): the same conditions as the bf16 one; bit-identical to conv16_kernel
+            const bool same = d.in_H == d.GH && d.in_W == d.GW && d.out_H == d.GH && d.out_W == d.GW;
+            const bool aw = d.tdh[0] == 0 && d.tdh[1] == 0 && d.tdh[2] == 0;
+            const bool ah = d.tdw[0] == 0 && d.tdw[1] == 0 && d.tdw[2] == 0;
+            if (g_sw_conv16_rows.on() && same && (aw || ah) && d.GW % 16 == 0) {    // (stream16_ok: 16-byte tensors, < 2^29 elements)
+#define ROWS_CASE(u, gg)                                                                            \
+                do {                                                                                \
+                    const unsigned blocks = (unsigned)((M + 64 * u * gg - 1) / (64 * u * gg));      \
+                    if (aw) conv16_rows_kernel<u, gg, true><<<blocks, 256, 0, st>>>(d);             \
+                    else conv16_rows_kernel<u, gg, false><<<blocks, 256, 0, st>>>(d);               \
+                } while (0)
+                if (grp >= 4) ROWS_CASE(4, 4);
+                else if (grp >= 2) ROWS_CASE(4, 2);
+                else ROWS_CASE(4, 1);
+#undef ROWS_CASE
+                CHECK_LAUNCH("conv16_rows_kernel");
+                return 0;
+            }
+        }
         if (grp >= 4) conv16_kernel<T, 3, 4, 4><<<(unsigned)((M + 1023) / 1024), 256, 0, st>>>(d);
         else if (grp >= 2) conv16_kernel<T, 3, 4, 2><<<(unsigned)((M + 511) / 512), 256, 0, st>>>(d);
         else conv16_kernel<T, 3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3_kernel(const 
             }
 #pragma unroll
             for (int i = 0; i < B; ++i)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i]), rout, (int)vo[i], (int)soff, 0);
+                buf_store4_soff(__builtin_bit_cast(u32x4, v[i]), rout, (int)vo[i], (int)soff);
         }
     };
     // Optional statistics of the output (train-mode BatchNorm: the tile holds conv + bias, no mask or

@@ -71,11 +71,26 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
     const bool lo_is_tap0 = d.s1[0] < 0;        // weight tap 0 reads line q - dil (forward) or q + dil (data gradient)
     const int Lc = d.lines_per_img / dil;       // lines per chain
     const int cpi = d.segs * dil;               // chains per image
-    const long long U = (long long)d.nlines * d.segs;
+    const unsigned U = (unsigned)(d.nlines * d.segs);       // (host: below 2^31)
     const unsigned G = gridDim.x;
     const unsigned bix = xcd_tile(blockIdx.x, G);
-    const int u0 = (int)((long long)bix * U / G), u1 = (int)((long long)(bix + 1) * U / G);
+    // contiguous shares of U / G outputs, the first U % G blocks one more (one 32-bit division)
+    const unsigned uq = U / G, ur = U - uq * G;
+    const int u0 = (int)(bix * uq + (bix < ur ? bix : ur)), u1 = u0 + (int)uq + (bix < ur ? 1 : 0);
     if (u0 >= u1) return;
+    // The epilogue constants are requested before anything else (buffer loads: an absent vector has no
+    // records and reads as zero; no branch near them, so nothing waits here) and land during the
+    // scalar set-up below.
+    float c_b, c_g, c_be, c_mu, c_va;
+    {
+        const unsigned cb = NC * 4u, vo = tid < NC ? (unsigned)tid * 4u : ERF_OOB;
+        const BnAffine &bn = d.epi1.bn;
+        c_b = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(d.epi1.bias, d.epi1.bias ? cb : 0u), (int)vo, 0, 0));
+        c_g = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(bn.gamma, bn.on && bn.gamma ? cb : 0u), (int)vo, 0, 0));
+        c_be = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(bn.beta, bn.on && bn.beta ? cb : 0u), (int)vo, 0, 0));
+        c_mu = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(bn.mean, bn.on ? cb : 0u), (int)vo, 0, 0));
+        c_va = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(bn.var, bn.on ? cb : 0u), (int)vo, 0, 0));
+    }
 #ifdef ERF_LINE_STAMPS
     int stamp_i = 0;
 #define X3R_STAMP()                                                                                \
@@ -154,12 +169,16 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
     Str nx = after;                                     // the line loaded while cv is split
     if (j > 0) { nx = cv; nx.x = j - 1; nx.soff = cv.soff - lstep; }
     X3R_STAMP();    // first loads issued
-    // (the constants before the weights: their loads sit behind branches, where the compiler waits for
-    // everything in flight — which must not include 144 KB of weight fragments per CU)
-    for (int c = tid; c < NC; c += 256) {
-        float sc, sh;
-        epi_channel_affine(d.epi1, c, sc, sh);
-        cst[c] = sc; cst[NC + c] = sh;
+    {   // epi_channel_affine's arithmetic on the values requested at the top
+        float sc = 1.0f, sh = c_b;
+        if (d.epi1.bn.on) {
+            const BnAffine &bn = d.epi1.bn;
+            const float inv = bn.var_is_invstd ? c_va : rsqrtf(c_va + bn.eps);
+            const float g = (bn.gamma ? c_g : 1.0f) * inv;
+            sh = (sh - c_mu) * g + c_be;
+            sc = g;
+        }
+        if (tid < NC) { cst[tid] = sc; cst[NC + tid] = sh; }
     }
 
     X3R_STAMP();    // constants done
@@ -404,7 +423,7 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const f32x4 v = f32x4{acc[a][4 * gq], acc[a][4 * gq + 1], acc[a][4 * gq + 2], acc[a][4 * gq + 3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (int)vo, (int)(soff + 32u * gq), 0);
+                buf_store4_soff(__builtin_bit_cast(u32x4, v), rout, (int)vo, (int)(soff + 32u * gq));
             }
             if (bits_out) {
                 unsigned wbits = 0u;

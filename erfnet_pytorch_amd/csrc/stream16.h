@@ -720,6 +720,136 @@ __global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv16_kernel<float> in the rows form of conv16_bf16_rows_kernel: images whose width is a multiple
+// of 16, taps along one axis.  A tile's image, row and first column are wave-uniform scalars, a lane's
+// share of every byte offset is a per-wave constant, residual / mask / output use the tile's byte
+// offset as the buffer instructions' scalar offset.  The products run in conv16_kernel's order
+// (tap, k-quarter, tile), so the results are bit-identical to it.  Operand vectors are converted from
+// the loads' integer vectors as WHOLE vectors: a bit cast applied to one element of a vector reads
+// element 0 with this compiler.
+template <int U, int G, bool AW>
+__global__ __launch_bounds__(256) void conv16_rows_kernel(const IgemmDesc d)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned W = (unsigned)d.GW, H = (unsigned)d.GH;
+    const unsigned M = (unsigned)d.N * H * W, GHW = H * W;
+    const unsigned base0 = ((unsigned)blockIdx.x * 4 + wave) * (16 * U * G);
+    __shared__ float wlds[768];
+    const float *wsrc = stage_w16(d, wlds);
+    if (base0 >= M) return;
+    const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, M * d.in_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(d.out, M * d.out_C * 4u);
+    const __amdgpu_buffer_rsrc_t r_res = make_rsrc(d.epi.res, d.epi.res ? M * d.epi.res_C * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, d.epi.mask ? M * d.epi.mask_C * 4u : 0u);
+    const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, d.epi.nscale ? (unsigned)d.N * 64u : 0u);
+    const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
+    const bool has_ns = d.epi.nscale != nullptr, has_mask = d.epi.mask != nullptr, has_res = d.epi.res != nullptr;
+
+    float wr[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wr[t][m] = wsrc[d.woff[t] + (4 * g + m) * d.wsk + i * d.wsn];
+
+    // a lane's constant part of the byte offsets, relative to the tile's first pixel (the tap loads
+    // may reach backwards: their sum with the tile's offset is non-negative whenever the tap lies
+    // inside the image), and the coordinate the bounds test looks at: column (AW) or row
+    int lane_in[3], rel[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        lane_in[t] = ((d.tdh[t] * (int)W + d.tdw[t] + i) * d.in_C + d.in_coff + 4 * g) * 4;
+        rel[t] = AW ? i + d.tdw[t] : d.tdh[t];
+    }
+    const unsigned lane_res = (unsigned)((i * d.epi.res_C + d.epi.res_coff + 4 * g) * 4);
+    const unsigned lane_mask = (unsigned)((i * d.epi.mask_C + d.epi.mask_coff + 4 * g) * 4);
+    const unsigned lane_out = (unsigned)((i * d.out_C + d.out_coff + 4 * g) * 4);
+    const unsigned res_px = (unsigned)d.epi.res_C * 4u, mask_px = (unsigned)d.epi.mask_C * 4u;
+    const unsigned in_px = (unsigned)d.in_C * 4u, out_px = (unsigned)d.out_C * 4u;
+
+    unsigned tn = base0 / GHW;
+    unsigned trem = base0 - tn * GHW;
+    unsigned tgi = trem / W, tgj = trem - tgi * W;
+    f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+    f32x4 sh = buf_load4(r_bias, g * 16u);
+    if (d.epi.bn.on) {          // wave-uniform
+        const f32x4 ga = *reinterpret_cast<const f32x4 *>(d.epi.bn.gamma + 4 * g);
+        const f32x4 be = *reinterpret_cast<const f32x4 *>(d.epi.bn.beta + 4 * g);
+        const f32x4 mu = *reinterpret_cast<const f32x4 *>(d.epi.bn.mean + 4 * g);
+        const f32x4 va = *reinterpret_cast<const f32x4 *>(d.epi.bn.var + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float inv = d.epi.bn.var_is_invstd ? va[r] : rsqrtf(va[r] + d.epi.bn.eps);
+            sc[r] = ga[r] * inv;
+            sh[r] = (sh[r] - mu[r]) * sc[r] + be[r];
+        }
+    }
+    const bool relu = d.epi.relu != 0;
+    const f32x4 zero4 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, one4 = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+
+    for (int grp = 0; grp < G; ++grp) {
+        const unsigned base = base0 + grp * (16 * U);
+        if (base >= M) break;
+        f32x4 xv[U][3], rres[U], rmask[U], rns[U];
+        unsigned opix[U];           // pixel index of the tile's first pixel | ERF_OOB beyond the end
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // wave-uniform: the tile's first pixel, its row / column, and whether the tile exists
+            const bool live = base + u * 16 < M;
+            const unsigned px0 = (tn * H + tgi) * W + tgj;
+            const unsigned lim = live ? (AW ? W : H) : 0u;          // a dead tile fails every bounds test
+            const unsigned pos = AW ? tgj : tgi;
+            const unsigned in0 = px0 * in_px;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const unsigned o = (pos + (unsigned)rel[t]) < lim ? in0 + (unsigned)lane_in[t] : ERF_OOB;
+                xv[u][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)o, 0, 0));
+            }
+            const unsigned dead = live ? 0u : ERF_OOB;
+            opix[u] = px0 | dead;
+            rres[u] = zero4;
+            rmask[u] = one4;
+            rns[u] = one4;
+            if (has_res) rres[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_res, (int)(lane_res | dead), (int)(px0 * res_px), 0));
+            if (has_mask) rmask[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_mask, (int)(lane_mask | dead), (int)(px0 * mask_px), 0));
+            if (has_ns) rns[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_ns, (int)(16u * g), (int)(tn * 64u), 0));
+            tgj += 16;                                   // uniform advance to the next tile
+            if (tgj >= W) {
+                tgj = 0;
+                if (++tgi == H) { tgi = 0; ++tn; }
+            }
+        }
+        f32x4 acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = zero4;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const float xe = xv[u][t][m];
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[t][m], xe, acc[u], 0, 0, 0);
+                }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = acc[u][r] * sc[r] + sh[r];
+                if (has_ns) e *= rns[u][r];
+                e += rres[u][r];
+                if (relu) e = fmaxf(e, 0.0f);
+                v[r] = rmask[u][r] > 0.0f ? e : 0.0f;
+            }
+            const unsigned dead = opix[u] & ERF_OOB;
+            buf_store4_soff(__builtin_bit_cast(u32x4, v), r_out, (int)(lane_out | dead), (int)((opix[u] & ~ERF_OOB) * out_px));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad16_kernel for bf16 tensors on v_mfma_f32_16x16x32_bf16 (32 pixels per instruction).  The
 // contraction index is the pixel while memory holds [pixel][channel]: a wave stages 32 pixels of G and
 // of X shifted by each tap (zero outside the image: three 16-byte loads per lane instead of forty-eight

@@ -419,13 +419,17 @@ def test_eight_wave_pair_kernel_in_a_training_step_is_bit_identical():
         assert torch.equal(u, v), i
 
 
-@pytest.mark.parametrize("dtype", [BF])
-@pytest.mark.parametrize("n,h,w", [(2, 10, 48), (3, 5, 16), (1, 7, 32), (2, 33, 64), (6, 64, 128)])
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+@pytest.mark.parametrize("n,h,w", [(2, 10, 48), (3, 5, 16), (1, 7, 32), (2, 33, 64), (6, 64, 128), (1, 256, 512),
+                                   (1, 512, 1024), (6, 256, 512)])
 def test_conv16_rows_kernel_equals_general_kernel(n, h, w, dtype):
-    """16-channel non_bottleneck_1d (the decoder's last stage, train/erfnet_blocks.py:33-73) on bf16
-    tensors whose width is a multiple of 16: the kernel with scalar tile coordinates
+    """16-channel non_bottleneck_1d (the decoder's last stage, train/erfnet_blocks.py:33-73) on bf16 and
+    fp32 tensors whose width is a multiple of 16: the kernel with scalar tile coordinates
     (ERF_OPT_CONV16_ROWS) against the general one — forward, input gradient and weight gradients bit
-    for bit; sizes that leave whole tiles beyond the end, one tile per row, several rows per wave."""
+    for bit; sizes that leave whole tiles beyond the end, one tile per row, several rows per wave, and
+    the sizes at which a wave takes two and four groups of tiles (the fp32 form stores 16 bytes per lane
+    with the tile's offset in a scalar register: a store whose data register was overwritten by the next
+    instruction showed up only there, in lanes 12-15 of some tiles, from run to run)."""
     from erfnet_pytorch_amd import _lib
     from erfnet_pytorch_amd.erfnet_blocks import non_bottleneck_1d
     torch.manual_seed(5)
