@@ -676,10 +676,10 @@ __global__ __launch_bounds__(256) void conv16_bf16_rows_kernel(const IgemmDesc d
                 if (++tgi == H) { tgi = 0; ++tn; }
             }
         }
-        // The products and the epilogue form ONE basic block per specialisation: an fp32 transcription
-        // of this kernel with a branch between the last MFMA and the first read of its result returned
-        // stale accumulator values in pixels 12-15 of a tile, and was right with the products inside
-        // the specialised block (the bf16 form was bit-identical to the general kernel either way).
+        // The products and the epilogue form one basic block per specialisation (no branch between the
+        // last MFMA and the first read of its result).  This kernel stores 8 bytes per lane; the wrong
+        // values once seen in pixels 12-15 of an fp32 sibling came from its 16-byte stores with a
+        // register offset (buf_store4_soff), not from the accumulators.
         auto finish = [&](auto relu_t, auto ns_t) __attribute__((always_inline)) {
             constexpr bool RELU = decltype(relu_t)::value, NS = decltype(ns_t)::value;
             f32x4 acc[U];
