@@ -151,3 +151,57 @@ def eval_encoder_layers(down, nb, p):
 
 def eval_decoder_layers(up, nb):
     return [up(128, 64), nb(64, 0, 1), nb(64, 0, 1), up(64, 16), nb(16, 0, 1), nb(16, 0, 1)]
+
+
+def regression_classes(module_name, small, ladder, late_dropout=0.1):
+    """``Encoder`` / ``Decoder`` / ``Net`` of one of the reference's four regression network files
+    (train/net_regression.py, net_regression_small.py, net_regression_ladder.py,
+    net_regression_ladder_small.py: the same three classes, differing in the number of 64- and
+    128-channel blocks and in the ladder connections), bound to ``module_name`` so that they pickle and
+    print as that file's classes."""
+    ref = "train/" + module_name.rsplit(".", 1)[-1] + ".py"
+
+    class Encoder(TrainEncoder):
+        def __init__(self, use_dropout=False):
+            super().__init__(use_dropout=use_dropout, n64=2 if small else 5,
+                             reps128=1 if small else 2, ladder=ladder)
+
+    class Decoder(TrainDecoder):
+        def __init__(self, softmax_classes, late_dropout_prob, likelihood_loss, use_dropout=False):
+            if softmax_classes:
+                head = "softmax"
+            else:
+                head = 2 if likelihood_loss else 1   # (mean, variance) or a single scalar map
+            super().__init__(head=head, late_dropout_prob=late_dropout_prob, use_dropout=use_dropout,
+                             small=small, ladder=ladder, softmax_classes=softmax_classes)
+
+    class Net(nn.Module):
+        __doc__ = f"reference {ref}: Net"
+
+        def __init__(self, encoder=None, softmax_classes=0, likelihood_loss=False,
+                     spread_class_power=False, late_dropout_prob=late_dropout):
+            super().__init__()
+            self.softmax_classes = softmax_classes
+            self.likelihood_loss = likelihood_loss
+            use_dropout = softmax_classes > 0
+            if softmax_classes > 0:
+                self.class_power = nn.Parameter(class_power_init(softmax_classes, spread_class_power,
+                                                                 0.0, 2.0))
+                self.class_power_var = nn.Parameter(torch.ones(1, softmax_classes, 1, 1))
+            self.encoder = Encoder(use_dropout=use_dropout) if encoder is None else encoder
+            self.decoder = Decoder(softmax_classes, late_dropout_prob, likelihood_loss,
+                                   use_dropout=use_dropout)
+
+        def forward(self, input):
+            enc = self.encoder(input)
+            out = self.decoder(*enc) if ladder else self.decoder(enc)
+            if self.softmax_classes > 0:
+                if self.likelihood_loss:
+                    return out, self.class_power, self.class_power_var
+                return out, self.class_power
+            return out
+
+    for cls in (Encoder, Decoder, Net):
+        cls.__module__ = module_name
+        cls.__qualname__ = cls.__name__
+    return Encoder, Decoder, Net

@@ -325,12 +325,14 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
         const bf16_t *mk2 = (const bf16_t *)d.epi2.mask;
         const unsigned *mkb2 = mk2 ? nullptr : d.epi2.mask_bits;
         unsigned mw[PASSES] = {};
+        __syncthreads();            // (pairs with A's set-up barrier)
+        // this role idles for a period: its weight fragments are requested behind the set-up barrier, so
+        // that the barrier's memory wait covers only role A's half of the CU's weight traffic
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 w2[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp2 + ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8);
-        __syncthreads();            // (pairs with A's set-up barrier)
         Geo g = geo(b0);
         if (res_last) issue_tile((const bf16_t *)d.epi2.res, g.base, g.len, OFF_RES);
         // idle period: A works on the first tile
