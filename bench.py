@@ -598,8 +598,11 @@ def main():
         if world == 1:
             del model, opt, params, reducer
             torch.cuda.empty_cache()
-            rec["roofline"] = (dominant_kernel_roofline_bf16(device, args.batch) if args.dtype == "bf16" else
-                               dominant_kernel_roofline(device, args.batch))
+        # the dominant kernel is timed on rank 0's device at every world size (one launch geometry per
+        # GPU whatever N is: the scaling is weak); the other ranks wait in the closing barrier meanwhile
+        rec["roofline"] = (dominant_kernel_roofline_bf16(device, args.batch) if args.dtype == "bf16" else
+                           dominant_kernel_roofline(device, args.batch))
+        if world == 1:
             if not args.no_extras:
                 other = "bf16" if args.dtype == "f32" else "f32"
                 rec["train_other_dtype"] = train_rate(device, args.model, other, args.batch, 10, 3)
