@@ -253,6 +253,17 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
     };
 
     if (K == 0) return;             // (block-uniform: no barrier has been executed yet)
+#ifdef ERF_LINE_STAMPS
+    int stamp_i = 0;                // diagnostic build: [block][role][64] stamps of each role's first wave
+#define L2_STAMP()                                                                                 \
+    do {                                                                                           \
+        if (d.stamps && ltid == 0 && stamp_i < 64)                                                 \
+            d.stamps[((size_t)blockIdx.x * 2 + (role_a ? 0 : 1)) * 64 + stamp_i++] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define L2_STAMP() do {} while (0)
+#endif
+    L2_STAMP();
     clear_acc();
     if (role_a) {
         // ================================================================= role A: conv_a, tile by tile
@@ -273,6 +284,7 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
             for (int s = 0; s < KS; ++s)
                 w1[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8);
         __syncthreads();            // set-up (constants, zero rows) visible; B executes the same barrier
+        L2_STAMP();                 // A1: set-up done
         for (int k = 0; k < K; ++k) {
             const bool more = k + 1 < K;
             Geo gn = g;
@@ -282,7 +294,9 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
             for (int t = 0; t < 3; ++t) {
                 const bool tv = tap_valid(g, t);            // wave-uniform
                 if (tv) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                L2_STAMP();         // A: tap landed
                 lds_barrier();                              // X1..X3
+                L2_STAMP();         // A: barrier passed
                 // (behind the tile's last wait for operand tiles: the words land during the last tap's MFMAs)
                 if (t == 2 && mkb1) fetch_bits(mkb1, mw, g);
                 if (!tv) continue;
@@ -307,12 +321,16 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
                 mma_tap(w1[t], rowp, x4);
                 ++seq;
             }
+            L2_STAMP();             // A: products done
             const int mid_off = OFF_MID + (k & 1) * MIDSZ;
             store_acc(d.epi1, cst, cst + NC, res_first, true, OFF_RESA, mid_off, g);
             clear_acc();
+            L2_STAMP();             // A: intermediate in LDS
             lds_barrier();                                  // X4
+            L2_STAMP();             // A: X4 passed
             if (d.mid || mk1 || mkb1)
                 sweep_tile(mid_off, mk1, mw, mkb1 != nullptr, d.mid, d.mid ? d.epi1.bits_out : nullptr, true, g);
+            L2_STAMP();             // A: pass over the intermediate done
             lds_barrier();                                  // X5
             g = gn;
         }
@@ -358,16 +376,24 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
                 }
                 mma_tap(w2[t], rowp, x4);
             }
+            L2_STAMP();             // B: products done
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the residual tile has landed (this wave's part)
+            L2_STAMP();             // B: memory wait done
             lds_barrier();                                  // X1
+            L2_STAMP();             // B: X1 passed
             store_acc(d.epi2, cst + 2 * NC, cst + 3 * NC, res_last, false, OFF_RES, OFF_RES, g);
             clear_acc();
+            L2_STAMP();             // B: result tile in LDS
             lds_barrier();                                  // X2
+            L2_STAMP();             // B: X2 passed
             sweep_tile(OFF_RES, mk2, mw, mkb2 != nullptr, d.out, d.epi2.bits_out, false, g);
+            L2_STAMP();             // B: output pass done
             lds_barrier();                                  // X3: the RES tile may be refilled
             if (more && res_last) issue_tile((const bf16_t *)d.epi2.res, gn.base, gn.len, OFF_RES);
             lds_barrier();                                  // X4
+            L2_STAMP();             // B: X4 passed
             lds_barrier();                                  // X5
+            L2_STAMP();             // B: X5 passed
             g = gn;
         }
     }
