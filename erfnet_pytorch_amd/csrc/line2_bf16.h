@@ -11,17 +11,23 @@
 // so each SIMD hosts one A wave and one B wave whose MFMAs fill each other's waits.  The arithmetic of
 // a tile is line_bf16_kernel's, instruction for instruction: results are bit-identical (tested).
 //
-// Synchronisation: s_barrier joins all eight waves, so both roles execute the SAME number of
-// barriers per period — five, whatever the tile's geometry — and the same number of periods (A: its
-// K tiles + one drain period; B: one idle period + its K tiles):
-//            A (tile k+1)                                   B (tile k)
-//   X1   tap 0 landed                                 residual tile landed, conv_b MFMAs issued
-//   X2   tap 1 landed                                 accumulators (+ residual) stored to the RES tile
-//   X3   tap 2 landed                                 output pass has read the RES tile
-//   X4   intermediate stored to MID                   -
-//   X5   intermediate's store / mask pass done        -            (B may read MID[(k+1) & 1] after X5)
-// A writes MID[(k+1) & 1] behind X3 of its period; B read that buffer (tile k-1) before X1 of the
-// period before: no further hand-shake is needed.
+// Synchronisation: s_barrier joins all eight waves, so both roles execute the SAME barriers: two per
+// period, whatever the tile's geometry, and the same number of periods (A: its K tiles + one drain
+// period; B: one idle period + its K tiles).  In period p role A works on tile p, role B on tile p - 1:
+//            A (tile p)                                       B (tile p - 1)
+//   wait     operand tiles of all three taps (+ residual)    residual tile of tile p - 1 landed,
+//            landed (requested behind beta of period p - 1)   output stores of tile p - 2 done
+//   alpha    ------------------------------------------------------------------------------------
+//            products of the three taps out of TAP[0..2],    request the residual tile of tile p;
+//            first epilogue into MID[p & 1]                   products out of MID[(p - 1) & 1], final
+//                                                             epilogue (+ residual) into RES[(p - 1) & 1]
+//   beta     ------------------------------------------------------------------------------------
+//            request the operand tiles of tile p + 1;         output pass over RES[(p - 1) & 1]
+//            store / mask pass over MID[p & 1]
+// One buffer per tap (all three operand tiles of a tile are in flight together), the intermediate and
+// B's residual / result tile double-buffered: a buffer is rewritten one barrier after its last reader
+// passed.  (Five barriers per period — one per tap buffer hand-over — left each role waiting for the
+// other in every interval: 7.4 k ticks per period for 2.7 k of products.)
 #pragma once
 #include "line_bf16.h"
 
@@ -37,10 +43,11 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
     constexpr int PASSES = BM * CPR / 256;
     static_assert(BM * CPR % 256 == 0, "whole copy passes");
     constexpr int MIDSZ = T + PITCH;                        // tile + zero row
-    constexpr int OFF_TAP = 0, OFF_MID = 2 * T, OFF_RES = OFF_MID + 2 * MIDSZ, OFF_RESA = OFF_RES + T;
+    constexpr int OFF_TAP = 0, OFF_MID = 3 * T, OFF_RES = OFF_MID + 2 * MIDSZ, OFF_RESA = OFF_RES + 2 * T;
     constexpr int OFF_CST = OFF_RESA + T;
     static_assert(OFF_CST + 4 * NC * 4 <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_CST + 4 * NC * 4];
+    __shared__ unsigned a_done;     // role A's waves that have finished reading the tap buffers (running count)
     float *cst = reinterpret_cast<float *>(lds + OFF_CST);        // sc1[NC] sh1[NC] sc2[NC] sh2[NC]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
         epi_channel_affine(d.epi2, c, sc, sh);
         cst[2 * NC + c] = sc; cst[3 * NC + c] = sh;
     }
+    if (tid == 0) a_done = 0u;
     for (int i = tid; i < 2 * (PITCH / 4); i += 512) {
         const int buf = i / (PITCH / 4), e = i % (PITCH / 4);
         reinterpret_cast<unsigned *>(lds + OFF_MID + buf * MIDSZ + T)[e] = 0u;
@@ -271,45 +279,37 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
         const bf16_t *mk1 = (const bf16_t *)d.epi1.mask;
         const unsigned *mkb1 = mk1 ? nullptr : d.epi1.mask_bits;
         unsigned mw[PASSES] = {};
-        int seq = 0;
         Geo g = geo(b0);
-        {
-            int t = 0;
-            while (!tap_valid(g, t)) ++t;
-            issue_tile(d.in, g.base + (unsigned)(tap_shift(t) * d.qstride), g.len, OFF_TAP);
-        }
+        auto request_taps = [&](const Geo &q) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (tap_valid(q, t)) issue_tile(d.in, q.base + (unsigned)(tap_shift(t) * d.qstride), q.len, OFF_TAP + t * T);
+        };
+        auto request_res = [&](const Geo &q) __attribute__((always_inline)) {
+            if (res_first) issue_tile((const bf16_t *)d.epi1.res, q.base, q.len, OFF_RESA);
+        };
+        request_taps(g);
+        request_res(g);
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 w1[t][s] = *reinterpret_cast<const bf16x8 *>(d.wp1 + ((size_t)((t * KS + s) * GC + cg) * 64 + lane) * 8);
         __syncthreads();            // set-up (constants, zero rows) visible; B executes the same barrier
-        L2_STAMP();                 // A1: set-up done
+        L2_STAMP();                 // A: set-up done
         for (int k = 0; k < K; ++k) {
             const bool more = k + 1 < K;
             Geo gn = g;
             if (more) gn = geo(b0 + (k + 1) * nblk);
-            if (res_first) issue_tile((const bf16_t *)d.epi1.res, g.base, g.len, OFF_RESA);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of the operand tiles
+            L2_STAMP();             // A: operand tiles landed
+            lds_barrier();                                          // alpha
+            L2_STAMP();             // A: alpha passed
+            if (mkb1) fetch_bits(mkb1, mw, g);                      // (land during the products)
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
-                const bool tv = tap_valid(g, t);            // wave-uniform
-                if (tv) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                L2_STAMP();         // A: tap landed
-                lds_barrier();                              // X1..X3
-                L2_STAMP();         // A: barrier passed
-                // (behind the tile's last wait for operand tiles: the words land during the last tap's MFMAs)
-                if (t == 2 && mkb1) fetch_bits(mkb1, mw, g);
-                if (!tv) continue;
-                int nt = t + 1;
-                while (nt < 3 && !tap_valid(g, nt)) ++nt;
-                if (nt < 3) {
-                    issue_tile(d.in, g.base + (unsigned)(tap_shift(nt) * d.qstride), g.len, OFF_TAP + ((seq + 1) & 1) * T);
-                } else if (more) {
-                    int ft = 0;
-                    while (!tap_valid(gn, ft)) ++ft;
-                    issue_tile(d.in, gn.base + (unsigned)(tap_shift(ft) * d.qstride), gn.len, OFF_TAP + ((seq + 1) & 1) * T);
-                }
-                const unsigned char *tb = lds + OFF_TAP + (seq & 1) * T;
+                if (!tap_valid(g, t)) continue;                     // wave-uniform
+                const unsigned char *tb = lds + OFF_TAP + t * T;
                 const unsigned char *rowp[WM];
                 unsigned x4[WM];
 #pragma unroll
@@ -319,24 +319,37 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
                     x4[a] = (unsigned)((line_swz<NC>(px) ^ h) << 4);
                 }
                 mma_tap(w1[t], rowp, x4);
-                ++seq;
             }
-            L2_STAMP();             // A: products done
+            L2_STAMP();             // A: products issued
+            // The tap buffers are free once the four A waves have their last fragments in registers: a
+            // hand-shake among them (a running count in LDS; role B is not involved) lets the next tile's
+            // operand tiles be requested a first epilogue earlier than the next barrier would.  The
+            // residual tile of the first epilogue is read there and follows behind beta.  (A mask read
+            // as a tensor inside the pass is waited for in issue order, i.e. behind these requests: by
+            // then they have had the first epilogue's time to land.)
+            if (more) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&a_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned want = 4u * (unsigned)(k + 1);
+                while (__hip_atomic_load(&a_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+                request_taps(gn);
+            }
+            L2_STAMP();             // A: next tiles requested
             const int mid_off = OFF_MID + (k & 1) * MIDSZ;
             store_acc(d.epi1, cst, cst + NC, res_first, true, OFF_RESA, mid_off, g);
             clear_acc();
             L2_STAMP();             // A: intermediate in LDS
-            lds_barrier();                                  // X4
-            L2_STAMP();             // A: X4 passed
+            lds_barrier();                                          // beta: tap buffers and residual tile are free
+            L2_STAMP();             // A: beta passed
+            if (more) request_res(gn);
             if (d.mid || mk1 || mkb1)
                 sweep_tile(mid_off, mk1, mw, mkb1 != nullptr, d.mid, d.mid ? d.epi1.bits_out : nullptr, true, g);
             L2_STAMP();             // A: pass over the intermediate done
-            lds_barrier();                                  // X5
             g = gn;
         }
         // drain period: B works on the last tile
-#pragma unroll
-        for (int x = 0; x < 5; ++x) lds_barrier();
+        lds_barrier();
+        lds_barrier();
     } else {
         // ================================================================= role B: conv_b + output, one tile behind
         bf16x8 w2[3][KS];
@@ -354,14 +367,20 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
         Geo g = geo(b0);
         if (res_last) issue_tile((const bf16_t *)d.epi2.res, g.base, g.len, OFF_RES);
         // idle period: A works on the first tile
-#pragma unroll
-        for (int x = 0; x < 5; ++x) lds_barrier();
+        lds_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // weights, first residual tile (this wave's share)
+        lds_barrier();
         for (int k = 0; k < K; ++k) {
             const bool more = k + 1 < K;
             Geo gn = g;
             if (more) gn = geo(b0 + (k + 1) * nblk);
-            const int mid_off = OFF_MID + (k & 1) * MIDSZ;
-            if (mkb2) fetch_bits(mkb2, mw, g);              // (land during this tile's MFMAs)
+            const int mid_off = OFF_MID + (k & 1) * MIDSZ, res_off = OFF_RES + (k & 1) * T;
+            L2_STAMP();             // B: period starts
+            lds_barrier();                                          // alpha
+            L2_STAMP();             // B: alpha passed
+            // the other result buffer was read for the last time before alpha: it takes the next residual tile
+            if (more && res_last) issue_tile((const bf16_t *)d.epi2.res, gn.base, gn.len, OFF_RES + ((k + 1) & 1) * T);
+            if (mkb2) fetch_bits(mkb2, mw, g);
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int sft = d.s2[t];
@@ -376,24 +395,17 @@ __global__ __launch_bounds__(512, 1) void line2_bf16_kernel(const LineDesc d)
                 }
                 mma_tap(w2[t], rowp, x4);
             }
-            L2_STAMP();             // B: products done
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the residual tile has landed (this wave's part)
-            L2_STAMP();             // B: memory wait done
-            lds_barrier();                                  // X1
-            L2_STAMP();             // B: X1 passed
-            store_acc(d.epi2, cst + 2 * NC, cst + 3 * NC, res_last, false, OFF_RES, OFF_RES, g);
+            L2_STAMP();             // B: products issued
+            store_acc(d.epi2, cst + 2 * NC, cst + 3 * NC, res_last, false, res_off, res_off, g);
             clear_acc();
             L2_STAMP();             // B: result tile in LDS
-            lds_barrier();                                  // X2
-            L2_STAMP();             // B: X2 passed
-            sweep_tile(OFF_RES, mk2, mw, mkb2 != nullptr, d.out, d.epi2.bits_out, false, g);
+            lds_barrier();                                          // beta
+            L2_STAMP();             // B: beta passed
+            // the next residual tile (requested behind alpha) has had the products' time to land; waiting
+            // here, in front of the pass's stores, keeps those stores out of every wait
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sweep_tile(res_off, mk2, mw, mkb2 != nullptr, d.out, d.epi2.bits_out, false, g);
             L2_STAMP();             // B: output pass done
-            lds_barrier();                                  // X3: the RES tile may be refilled
-            if (more && res_last) issue_tile((const bf16_t *)d.epi2.res, gn.base, gn.len, OFF_RES);
-            lds_barrier();                                  // X4
-            L2_STAMP();             // B: X4 passed
-            lds_barrier();                                  // X5
-            L2_STAMP();             // B: X5 passed
             g = gn;
         }
     }
