@@ -605,7 +605,7 @@ def main():
         if world == 1:
             if not args.no_extras:
                 other = "bf16" if args.dtype == "f32" else "f32"
-                rec["train_other_dtype"] = train_rate(device, args.model, other, args.batch, 10, 3)
+                rec["train_other_dtype"] = train_rate(device, args.model, other, args.batch, 30, 8)
                 rec["forward_time_harness"] = forward_time_harness(device, HEIGHT, WIDTH, "f32")
                 # BASELINE configs[2]: eval_forwardTime.py path, erfnet_nobn, bf16, 1024x2048
                 full = forward_time_harness(device, 2 * HEIGHT, 2 * WIDTH, "bf16")
@@ -613,9 +613,9 @@ def main():
                 full["f32_ms_per_img_min"] = forward_time_harness(device, 2 * HEIGHT, 2 * WIDTH, "f32",
                                                                   iters=10)["ms_per_img_min"]
                 rec["fullres_inference_bf16"] = full
-                rec["train_erfnet_bn"] = train_rate(device, "erfnet_bn", args.dtype, args.batch, 8, 3)
+                rec["train_erfnet_bn"] = train_rate(device, "erfnet_bn", args.dtype, args.batch, 20, 6)
                 rec["train_erfnet_bn_other_dtype"] = train_rate(device, "erfnet_bn", "bf16" if args.dtype == "f32" else "f32",
-                                                                args.batch, 8, 3)
+                                                                args.batch, 20, 6)
                 # BASELINE configs[4] per GPU: the ImageNet pre-training step of the encoder
                 rec["imagenet_pretrain"] = {"f32": imagenet_rate(device, "f32"),
                                             "bf16": imagenet_rate(device, "bf16")}
