@@ -590,6 +590,9 @@ __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
     const Epilogue &ep = d.epi;
     const bool has_res = ep.res != nullptr, has_mask = ep.mask != nullptr, has_ns = ep.nscale != nullptr;
     const bool relu = ep.relu != 0;
+    // (host: C % 32 == 0 when given) the output's "> 0" bits, word [row][c / 32], bit c % 32: a thread
+    // holds four of them, eight consecutive lanes a word
+    unsigned *const bits_out = ep.bits_out;
     // ROWS_U rows per trip with every load issued before the first use: a wave keeps ROWS_U 16-byte
     // loads per tensor in flight (a single one left the memory system under-subscribed: 2.9 TB/s)
     auto finish = [&](long long r, f32x4 v, f32x4 ns, f32x4 rs, f32x4 mk) __attribute__((always_inline)) {
@@ -613,6 +616,16 @@ __global__ __launch_bounds__(256) void elt_rows_kernel(const EltDesc d)
             for (int e = 0; e < 4; ++e) o[e] = mk[e] > 0.0f ? o[e] : 0.0f;
         }
         Act<T>::st4(d.out, r * C + c, o);
+        if (bits_out) {
+            unsigned w = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w |= (o[e] > 0.0f ? 1u : 0u) << e;
+            w <<= (unsigned)(c & 31);
+            w |= (unsigned)__shfl_xor((int)w, 1);
+            w |= (unsigned)__shfl_xor((int)w, 2);
+            w |= (unsigned)__shfl_xor((int)w, 4);
+            if ((threadIdx.x & 7) == 0) bits_out[r * (C / 32) + (c >> 5)] = w;
+        }
     };
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const long long stride = (long long)gridDim.x * RP;

@@ -1323,18 +1323,31 @@ unsigned rows_grid(long long steps)
     return (unsigned)(steps < 1 ? 1 : (steps < 2048 ? steps : 2048));
 }
 
+// Whether the element-wise pass takes the row-structured kernel (which can also leave the output's
+// "> 0" bits: fp32 tensors, C a multiple of 32).
+bool elt_rows_ok(const void *in, const void *out, const Epilogue &epi, int C)
+{
+    if (C % 4) return false;
+    const int C4 = C / 4;
+    return C4 <= 256 && 256 % C4 == 0 && aligned16(in) && aligned16(out) &&
+           (!epi.res || (epi.res_C % 4 == 0 && epi.res_coff % 4 == 0 && aligned16(epi.res))) &&
+           (!epi.mask || (epi.mask_C % 4 == 0 && epi.mask_coff % 4 == 0 && aligned16(epi.mask))) &&
+           (!epi.nscale || aligned16(epi.nscale));
+}
+bool elt_writes_bits(int dt, const void *in, const void *out, const Epilogue &epi, int C)
+{
+    return dt == 0 && C % 32 == 0 && elt_rows_ok(in, out, epi, C);
+}
 int launch_elt(int dt, const void *in, void *out, const Epilogue &epi, long long M, int C, int pix_per_image,
                hipStream_t st)
 {
     if (C % 4) return fail("element-wise pass needs C %% 4 == 0 (C = %d)", C);
     EltDesc e = {in, out, epi, M, C, pix_per_image};
-    const int C4 = C / 4;
-    const bool rows = C4 <= 256 && 256 % C4 == 0 && aligned16(in) && aligned16(out) &&
-                      (!epi.res || (epi.res_C % 4 == 0 && epi.res_coff % 4 == 0 && aligned16(epi.res))) &&
-                      (!epi.mask || (epi.mask_C % 4 == 0 && epi.mask_coff % 4 == 0 && aligned16(epi.mask))) &&
-                      (!epi.nscale || aligned16(epi.nscale));
+    const bool rows = elt_rows_ok(in, out, epi, C);
+    if ((epi.bits_out || epi.mask_bits) && !(epi.bits_out && !epi.mask_bits && elt_writes_bits(dt, in, out, epi, C)))
+        return fail("element-wise pass: mask bits are written by the row-structured fp32 kernel only");
     if (rows) {
-        const long long steps = (M * C4 + 255) / 256;
+        const long long steps = (M * (C / 4) + 255) / 256;
         BY_DT(dt, (elt_rows_kernel<T><<<rows_grid(steps), 256, 0, st>>>(e)));
     } else {
         BY_DT(dt, (elt_kernel<T><<<grid_for(M * (C / 4)), 256, 0, st>>>(e)));
@@ -1984,6 +1997,10 @@ int nb1d_chain_segment(int dt, const void *x, const erf_nb1d_block_t *blk, int n
                 Epilogue e = kNoEpi;
                 e.bn = P.m1 == 2 ? bn_saved_affine(B.bn1) : bn_eval_affine(B.bn1);
                 e.relu = 1;
+                if (B.sign_bits && B.sign_bits[1] && B.sign_bits_written && elt_writes_bits(dt, P.p2, P.t2, e, C)) {
+                    e.bits_out = B.sign_bits[1];        // t2 = relu(bn1(.)): the normalisation pass writes its mask
+                    *B.sign_bits_written |= 2u;
+                }
                 if (launch_elt(dt, P.p2, P.t2, e, M, C, H * W, st)) return 1;
             }
             if (run_igemm(P.d[2], st)) return 1;
@@ -2002,6 +2019,10 @@ int nb1d_chain_segment(int dt, const void *x, const erf_nb1d_block_t *blk, int n
             e.nscale = B.drop_scale;
             e.res = xin; e.res_C = C; e.res_coff = 0;
             e.relu = 1;
+            if (B.sign_bits && B.sign_bits[3] && B.sign_bits_written && elt_writes_bits(dt, P.p4, B.y, e, C)) {
+                e.bits_out = B.sign_bits[3];
+                *B.sign_bits_written |= 8u;
+            }
             if (launch_elt(dt, P.p4, B.y, e, M, C, H * W, st)) return 1;
         }
     }

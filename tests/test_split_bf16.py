@@ -173,12 +173,13 @@ def _pack_sign_bits(t):
 def _expected_bits_fp32(C_, H, W, dils, bn_mode):
     """Rolling kernel: a convolution along H takes the image rows as lines (H of them, W pixels long),
     one along W the columns; it wants 64-pixel tiles (128 channels: lines longer than 32 pixels) and
-    line counts that divide by the dilation.  Behind a BatchNorm pass the ReLU is not the convolution's."""
+    line counts that divide by the dilation.  Behind a BatchNorm the ReLU is the normalisation pass's."""
     out = []
     for d in dils:
         geo = [(H, W, 1), (W, H, 1), (H, W, d), (W, H, d)]
         fits = [(C_ == 64 or length > 32) and lines % dl == 0 for lines, length, dl in geo]
-        out.append(sum(1 << k for k in range(4) if fits[k] and not (bn_mode and k in (1, 3))))
+        # (behind a BatchNorm the ReLU belongs to the normalisation pass, which always writes its bits)
+        out.append(sum(1 << k for k in range(4) if fits[k] or (bn_mode and k in (1, 3))))
     return out
 
 
