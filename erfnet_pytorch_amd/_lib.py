@@ -40,6 +40,14 @@ class Nb1dBlockStruct(C.Structure):
                 ("sign_bits", C.POINTER(vp)), ("sign_bits_written", C.POINTER(C.c_uint))]
 
 
+# No packed fp32 arithmetic (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): on gfx950 one such instruction
+# issued behind a v_mfma_f32_32x32x16_bf16 holds the next MFMA of that SIMD back by about 16 cycles
+# (scripts/ubench/bf16_mfma_rate.hip: 33 -> 49.5 cycles per MFMA with one of them per MFMA, whereas four
+# plain v_fma_f32 / v_sub_f32 in the same place cost one cycle), and the line kernels place their fp32
+# splits and epilogues exactly there.  The element-wise kernels are bound by memory either way.
+DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+
+
 def sources():
     return [os.path.join(_SRC, f) for f in sorted(os.listdir(_SRC))] + \
         [os.path.join(os.path.dirname(_HERE), "include", "erfnet_hip.h")]
@@ -52,7 +60,7 @@ def build(force=False, verbose=False):
             os.path.getmtime(_SO) >= max(os.path.getmtime(s) for s in srcs):
         return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *DEVICE_FLAGS,
            "-o", _SO, os.path.join(_SRC, "erfnet_hip.hip")]
     if verbose:
         print(" ".join(cmd))

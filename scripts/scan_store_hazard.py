@@ -20,6 +20,7 @@ def listing():
         return open(sys.argv[1]).read()
     out = os.path.join(tempfile.mkdtemp(), "erfnet_hip.s")
     subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17",
+                           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",      # (the library's flags)
                            "--cuda-device-only", "-S", os.path.join(ROOT, "erfnet_pytorch_amd", "csrc", "erfnet_hip.hip"),
                            "-o", out], stderr=subprocess.DEVNULL)
     return open(out).read()
