@@ -21,6 +21,7 @@ pre-training step of imagenet/erfnet_imagenet.py.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -215,6 +216,22 @@ def line_conv_roofline(device, batch, c, div, dil):
             "hbm_gbs": round(nbytes / t / 1e9, 1), "hbm_frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
             "hbm_floor_us": round(hbm_floor_us, 2),
             "share_of_step": step_share(name)}
+
+
+def mfma_calibration():
+    """What the matrix pipe sustains on this box: scripts/ubench/bf16_mfma_rate (built by
+    __graft_entry__.build()) runs a bare v_mfma_f32_32x32x16_bf16 loop on every SIMD, once on constant and
+    once on random operands.  The instruction takes 32 cycles either way, but with toggling operands the
+    part holds a lower clock, so the data-sheet peak (2.4 GHz) is not what any kernel with real data can
+    reach.  Reported beside `roofline`, never in place of `peak`.  None when the binary is missing."""
+    exe = os.path.join(ROOT, "scripts", "ubench", "bf16_mfma_rate")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "calib"], capture_output=True, text=True, timeout=60)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:          # a diagnostic: never fails the bench line
+        return {"error": str(e)[:200]}
 
 
 def dominant_kernel_roofline(device, batch):
@@ -603,6 +620,14 @@ def main():
         rec["roofline"] = (dominant_kernel_roofline_bf16(device, args.batch) if args.dtype == "bf16" else
                            dominant_kernel_roofline(device, args.batch))
         if world == 1:
+            cal = mfma_calibration()
+            if cal and "random_operands_tflops" in cal:
+                r = rec["roofline"]
+                # bf16 MFMA work the timed kernel executes: six terms per fp32 product, one per bf16 product
+                executed = (r["achieved"] if args.dtype == "bf16" else 6.0 * r["tflops"])
+                cal["kernel_bf16_mfma_tflops"] = round(executed, 1)
+                cal["kernel_frac_of_random_operands_rate"] = round(executed / cal["random_operands_tflops"], 4)
+            rec["roofline"]["mfma_calibration"] = cal
             if not args.no_extras:
                 other = "bf16" if args.dtype == "f32" else "f32"
                 rec["train_other_dtype"] = train_rate(device, args.model, other, args.batch, 30, 8)

@@ -10,11 +10,13 @@
 //   mode 10..24 (second argument given): mode 0 + NV copies of one vector instruction kind behind every MFMA
 //   mode 8: mode 0 + one 8-byte LDS write per two MFMAs
 //   mode 3: mode 0 with the weight operand taken from a different register set every MFMA (24 sets)
+// `bf16_mfma_rate calib` prints one JSON line for bench.py (bare loop, constant against random operands).
 // Prints wall time per MFMA and SIMD, the s_memtime ticks per MFMA, and the clock both imply.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/ubench/bf16_mfma_rate.hip -o scripts/ubench/bf16_mfma_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <algorithm>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -97,8 +99,11 @@ __global__ __launch_bounds__(256, WPS) void rate_kernel(const u32x4 *src, float 
     if (tid == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
+struct Rate { double tflops, ticks_per_mfma, ghz; };
+static bool g_quiet = false;
+
 template <int MODE, int WPS, int DIST = 6>
-void run(const u32x4 *src, float *out, unsigned long long *tk, int iters)
+Rate run(const u32x4 *src, float *out, unsigned long long *tk, int iters)
 {
     const int grid = 256 * WPS;
     hipEvent_t e0, e1;
@@ -119,9 +124,18 @@ void run(const u32x4 *src, float *out, unsigned long long *tk, int iters)
     const double ns_per_mfma_simd = us * 1e3 / (n_per_wave * WPS);
     const double ticks_per_mfma_simd = (double)h[grid / 2] / (n_per_wave * WPS);
     const double tflops = 256.0 * 4 * WPS * n_per_wave * 32768.0 / (us * 1e-6) / 1e12;
-    printf("mode %d dist %d, %d wave(s) per SIMD, %d x 96 MFMAs per wave: %.1f us per launch, %.2f ns and %.1f ticks per MFMA and SIMD "
+    if (!g_quiet) printf("mode %d dist %d, %d wave(s) per SIMD, %d x 96 MFMAs per wave: %.1f us per launch, %.2f ns and %.1f ticks per MFMA and SIMD "
            "(tick = %.3f ns), %.0f TFLOP/s\n", MODE, DIST, WPS, iters, us, ns_per_mfma_simd, ticks_per_mfma_simd,
            ns_per_mfma_simd / ticks_per_mfma_simd, tflops);
+    return Rate{tflops, ticks_per_mfma_simd, ticks_per_mfma_simd / ns_per_mfma_simd};
+}
+
+static void fill_random(u32x4 *src)
+{   // operands of random sign, exponent around 1, random mantissa (toggling data costs power)
+    std::vector<unsigned short> hsrc(1024 * 8);
+    unsigned long long z = 88172645463325252ull;
+    for (auto &v : hsrc) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; v = (unsigned short)(((z >> 20) & 0x80ff) | ((0x7c + ((z >> 40) & 7)) << 7)); }
+    CK(hipMemcpy(src, hsrc.data(), 1024 * 16, hipMemcpyHostToDevice));
 }
 
 template <int MODE>
@@ -136,11 +150,25 @@ void kinds(const char *name, const u32x4 *src, float *out, unsigned long long *t
 
 int main(int argc, char **argv)
 {
-    const int iters = argc > 1 ? atoi(argv[1]) : 9;    // 9 x 96 = 864 MFMAs per wave: a line_x3r launch at 128 channels
+    const int iters = argc > 1 && atoi(argv[1]) > 0 ? atoi(argv[1]) : 9;    // 9 x 96 = 864 MFMAs per wave: a line_x3r launch at 128 channels
     const bool all = argc > 2;
     u32x4 *src; float *out; unsigned long long *tk;
     CK(hipMalloc(&src, 1024 * 16)); CK(hipMalloc(&out, 512 * 256 * 4)); CK(hipMalloc(&tk, 512 * 8));
     CK(hipMemset(src, 0x3c, 1024 * 16));
+    if (argc > 1 && !strcmp(argv[1], "calib")) {
+        // one JSON line: the bare MFMA loop (one wave per SIMD, 17280 MFMAs per wave) on constant and on
+        // random operands — same cycles per MFMA, but the clock the part sustains differs
+        g_quiet = true;
+        const Rate c = run<0, 1>(src, out, tk, 180);
+        fill_random(src);
+        const Rate r = run<0, 1>(src, out, tk, 180);
+        printf("{\"kernel\": \"v_mfma_f32_32x32x16_bf16 loop, 256 blocks x 4 waves, 17280 MFMAs per wave\", "
+               "\"constant_operands_tflops\": %.0f, \"constant_operands_clock_ghz\": %.2f, "
+               "\"random_operands_tflops\": %.0f, \"random_operands_clock_ghz\": %.2f, \"cycles_per_mfma\": %.1f}\n",
+               c.tflops, c.ghz, r.tflops, r.ghz, r.ticks_per_mfma);
+        return 0;
+    }
+    if (getenv("RATE_RANDOM")) { fill_random(src); printf("random operands\n"); }
     run<0, 1>(src, out, tk, iters);
     run<3, 1>(src, out, tk, iters);
     run<1, 1, 1>(src, out, tk, iters);
