@@ -284,7 +284,8 @@ __global__ __launch_bounds__(GI *GJ *KG * 64, MINB) void wgrad_line_x3_kernel(co
 #pragma unroll
                     for (int a = 0; a < IB; ++a)
                         xf[p][t][a] = tr_frag(Xs + p * XSZ, PITCH, 16 * ks + t * dil, (wi * IB + a) * 32, lane);
-            if (wi == 0) {      // column sums of G (the bias gradient): one wave row adds them up
+            {   // column sums of G (the bias gradient): every wave row adds them up (no branch in the
+                // k-step sequence: the scheduler moves fragment reads across k-steps), row 0 stores them
 #pragma unroll
                 for (int b = 0; b < JB; ++b)
 #pragma unroll
