@@ -59,6 +59,9 @@ def parse():
                     help="storage type of the activations (parameters and their gradients stay fp32)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra keys (bf16 rates, harnesses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="skip the matrix-pipe calibration (a child program; use under a profiler, whose "
+                         "preloaded library has initialised the GPU before this script starts)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks as child processes even for --gpus 1 (for --gpus N > 1 without a "
                          "launcher's WORLD_SIZE in the environment this is what happens anyway)")
@@ -371,21 +374,29 @@ def nb1d_bandwidth(device, height, width, dtype_name):
 
 
 def train_rate(device, model_name, dtype_name, batch, steps, warmup):
-    """images/s of the training step at one GPU (no reducer): extra keys only."""
+    """images/s of the training step at one GPU, built like the headline step: extra keys only."""
     from erfnet_pytorch_amd import optim
     from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d
     torch.manual_seed(0)
+    from erfnet_pytorch_amd.ddp import GradientReducer
     model = build_model(model_name).to(device).train()
-    opt = optim.Adam(model.parameters(), 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
     crit = CrossEntropyLoss2d()
     g = torch.Generator(device="cpu").manual_seed(1000)
     images = torch.rand(batch, 3, HEIGHT, WIDTH, generator=g).to(device).to(act_dtype(dtype_name))
     labels = torch.randint(-1, CLASSES, (batch, HEIGHT, WIDTH), generator=g).to(device)
+    # the headline step's set-up: gradients written into flat buckets, parameters flattened beside them,
+    # the library's Adam on the flat buffers
+    reducer = GradientReducer(model, bucket_bytes=3_600_000, direct_write=True)
+    reducer.zero_grad()
+    crit(logits_of(model(images)), labels).backward()
+    reducer.finish()
+    opt = optim.Adam(reducer.flatten_parameters(), 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        reducer.zero_grad()
         loss = crit(logits_of(model(images)), labels)
         loss.backward()
+        reducer.finish()
         opt.step()
         return loss
     for _ in range(warmup):
@@ -508,6 +519,8 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE is {world}; using {world}", file=sys.stderr)
+    # the matrix-pipe calibration is a child program: it runs before this process has touched the GPU
+    cal = mfma_calibration() if world == 1 and not args.no_calibration else None
     local_rank %= ndev                  # (only reachable with a non-RCCL rehearsal backend)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -620,7 +633,6 @@ def main():
         rec["roofline"] = (dominant_kernel_roofline_bf16(device, args.batch) if args.dtype == "bf16" else
                            dominant_kernel_roofline(device, args.batch))
         if world == 1:
-            cal = mfma_calibration()
             if cal and "random_operands_tflops" in cal:
                 r = rec["roofline"]
                 # bf16 MFMA work the timed kernel executes: six terms per fp32 product, one per bf16 product

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $out/bench.json 2> $out/log.txt
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-calibration "$@" > $out/bench.json 2> $out/log.txt
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 cp $f $out/stats.csv
 head -12 $out/stats.csv
