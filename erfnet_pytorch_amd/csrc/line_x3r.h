@@ -41,9 +41,6 @@ __device__ __forceinline__ unsigned x3r_opaque(unsigned v)
 #ifndef X3R_PFA128
 #define X3R_PFA128 1
 #endif
-#ifndef X3R_SPREAD
-#define X3R_SPREAD 1
-#endif
 template <int NC, int BM>
 __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const LineDesc d)
 {
@@ -55,7 +52,7 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
     constexpr int F4R = NC / 4;                 // 16-byte chunks per fp32 pixel row
     constexpr int RPP = 256 / F4R;              // rows per copy pass of the block
     constexpr int PASSES = BM / RPP;            // float4 per thread and tile
-    static_assert(KS % PASSES == 0 && (WM == 1 || PASSES == KS) && PASSES % 2 == 0 && (KS * WM) % (PASSES / 2) == 0, "conversion schedule");
+    static_assert(KS % PASSES == 0 && (WM == 1 || PASSES == KS), "conversion schedule");
     constexpr int CSTRIDE = KS / PASSES;
     constexpr int OFF_CST = 3 * T3;
     constexpr int LDS_BYTES = OFF_CST + 2 * NC * 4;
@@ -235,12 +232,9 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
     // One step: the MFMAs of one tap over the line tile at rd (6 x WM per k-step: terms lh hl mm mh hm
     // hh), and with JOB the split of the staged line into the slot at wr_off plus the loads of the
     // line after it, one piece behind each MFMA.
-    // JOB: 0 none, 1 the whole split in this step, 2 / 3 its first / second half (the steady state spreads
-    // a line's split over the centre and the lo step of an output: about three vector instructions per
-    // MFMA, which issue in the MFMA's shadow; six per MFMA — the whole split in one step — do not)
     auto run_step = [&](auto slot_c, auto job_c, auto first_c, int rd, int wr_off, const Str &ldn) __attribute__((always_inline)) {
         constexpr int SL = decltype(slot_c)::value;
-        constexpr int JOB = decltype(job_c)::value;
+        constexpr bool JOB = decltype(job_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;    // the block's first step: fetches the other slots' weights
         constexpr int OT1 = SL == 0 ? 1 : 0, OT2 = SL == 2 ? 1 : 2;
         const unsigned char *tb = lds + rd;
@@ -305,28 +299,19 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
                     if (term == 4) xm[a] = *reinterpret_cast<const bf16x8 *>(rowp[a] + TP + o);
                 }
                 if (FIRST && jj < 6) w[jj % 3][jj < 3 ? OT1 : OT2][s] = w_frag(jj % 3, jj < 3 ? OT1 : OT2, s);
-                if (JOB == 1) {
+                if (JOB) {
                     if (WM == 1) {
                         if (s % CSTRIDE == 0) piece(s / CSTRIDE, jj);
                     } else if (jj >= 6) {
                         piece(s, jj - 6);
                     }
-                } else if (JOB >= 2) {
-                    // half the passes over the step's KS * 6 * WM MFMAs: a piece behind every R-th
-                    constexpr int HP = PASSES / 2, R = KS * WM / HP;
-                    const int m = s * 6 * WM + jj;
-                    if (m % R == R - 1) piece((JOB == 3 ? HP : 0) + (m / R) / 6, (m / R) % 6);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
-    using J0 = std::integral_constant<int, 0>;
-    using J1 = std::integral_constant<int, 1>;
-    using JA = std::integral_constant<int, 2>;
-    using JB = std::integral_constant<int, 3>;
-    using F0 = std::false_type;
-    using F1 = std::true_type;
+    using J1 = std::true_type;
+    using J0 = std::false_type;
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
@@ -482,31 +467,26 @@ __global__ __launch_bounds__(256, (NC == 64 ? 2 : 1)) void line_x3r_kernel(const
             // the first centre step fetches the other taps' weights; it hosts the split of line j-1, or
             // (no line below) of the line the steps after it need
             if (cv.len != 0) {
-                run_step(S1{}, J1{}, F1{}, o_c, lo_valid ? o_lo : o_hi, nx);
+                run_step(S1{}, J1{}, J1{}, o_c, lo_valid ? o_lo : o_hi, nx);
                 job_done();
             } else {
-                run_step(S1{}, J0{}, F1{}, o_c, o_hi, nx);
+                run_step(S1{}, J0{}, J1{}, o_c, o_hi, nx);
             }
         } else if (!lo_valid && cv.len != 0) {      // a run's first output: the next line is split here
-            run_step(S1{}, J1{}, F0{}, o_c, o_hi, nx);
+            run_step(S1{}, J1{}, J0{}, o_c, o_hi, nx);
             job_done();
-        } else if (X3R_SPREAD && lo_valid && cv.len != 0) {
-            // steady state: the first half of the next line's split (its slot was read for the last time
-            // before the previous output's barrier), the second half follows in the lo step
-            run_step(S1{}, JA{}, F0{}, o_c, o_hi, nx);
         } else {
-            run_step(S1{}, J0{}, F0{}, o_c, o_hi, nx);
+            run_step(S1{}, J0{}, J0{}, o_c, o_hi, nx);
         }
         if (lo_valid) {
             if (cv.len != 0) {          // line j+1, or (chain end) the first line of the next run
-                if (FIRST || !X3R_SPREAD) run_step(S0{}, J1{}, F0{}, o_lo, o_hi, nx);
-                else run_step(S0{}, JB{}, F0{}, o_lo, o_hi, nx);
+                run_step(S0{}, J1{}, J0{}, o_lo, o_hi, nx);
                 job_done();
             } else {
-                run_step(S0{}, J0{}, F0{}, o_lo, o_hi, nx);
+                run_step(S0{}, J0{}, J0{}, o_lo, o_hi, nx);
             }
         }
-        if (hi_valid) run_step(S2{}, J0{}, F0{}, o_hi, o_hi, nx);
+        if (hi_valid) run_step(S2{}, J0{}, J0{}, o_hi, o_hi, nx);
         X3R_STAMP();
         finish(ok.base + (unsigned)j * lstep, ok.len);
         X3R_STAMP();
