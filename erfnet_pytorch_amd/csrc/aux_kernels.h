@@ -24,11 +24,16 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
 {
     __shared__ float ws[FD_MAX_CC * 28];
     const int Cout = d.Cc + 3;
-    for (int i = threadIdx.x; i < d.Cc * 28; i += 256) {
-        const int co = i / 28, e = i % 28;
-        ws[i] = e < 27 ? d.w[co * 27 + e] : 0.0f;
+    // the network's own first block (3 -> 16 channels) reads its weights through the scalar data path
+    // (below); every other shape stages them in LDS
+    const bool own = d.Cc == 13 && !d.epi.nscale && !d.epi.res && !d.epi.mask;
+    if (!own) {
+        for (int i = threadIdx.x; i < d.Cc * 28; i += 256) {
+            const int co = i / 28, e = i % 28;
+            ws[i] = e < 27 ? d.w[co * 27 + e] : 0.0f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     const int Ho = d.H / 2, Wo = d.W / 2;
     const long long M = (long long)d.N * Ho * Wo;
     const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -71,15 +76,20 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
                 }
     }
     const long long o0 = m * Cout;
-    if (d.Cc == 13 && !d.epi.nscale && !d.epi.res && !d.epi.mask) {
-        // the network's own first block (3 -> 16 channels): all 16 outputs of the pixel are formed
-        // in registers and leave as four 16-byte stores (same arithmetic as the general path below)
+    if (own) {
+        // all 16 outputs of the pixel are formed in registers and leave as four 16-byte stores (same
+        // arithmetic as the general path below).  The 351 weights are the same for every thread: read
+        // through the constant address space they arrive by scalar loads and enter the multiply-adds as
+        // scalar operands — staged in LDS, the compiler read all of them ahead of the first multiply-add
+        // into 351 vector registers, which left the kernel one wave per SIMD.
+        typedef const float __attribute__((address_space(4))) *const_f32;
+        const const_f32 wc = (const_f32)(unsigned long long)d.w;
         float v[16];
 #pragma unroll
         for (int co = 0; co < 13; ++co) {
             float acc = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 27; ++e) acc = fmaf(xin[e], ws[co * 28 + e], acc);
+            for (int e = 0; e < 27; ++e) acc = fmaf(xin[e], wc[co * 27 + e], acc);
             float sc, sh;
             epi_channel_affine(d.epi, co, sc, sh);
             v[co] = acc * sc + sh;
