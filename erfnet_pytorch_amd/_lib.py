@@ -72,6 +72,10 @@ _PROTOS = {
     "erf_version": (C.c_int, []),
     "erf_last_error": (C.c_char_p, []),
     "erf_launch_count": (C.c_ulonglong, []),
+    "erf_batch_begin": (C.c_int, []),
+    "erf_batch_pack": (C.c_int, [vp]),
+    "erf_batch_end": (C.c_int, [vp]),
+    "erf_batch_abort": (None, []),
     "erf_set_option": (C.c_int, [C.c_int, C.c_int]),
     "erf_workspace_bytes": (C.c_size_t, [ll, C.c_int]),
     "erf_downsampler_forward": (C.c_int, [vp, ll, ll, ll, ll, vp, vp, C.POINTER(BnStruct), vp, vp,
@@ -152,7 +156,7 @@ BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
 OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16, OPT_PAIR16, OPT_LINE2, OPT_SPLIT_BF16, OPT_CONV16_ROWS, OPT_X3_ROLL = 1, 2, 3, 4, 5, 6, 7, 8
 
 EXPORTS = tuple(_PROTOS)
-ABI_VERSION = 103                         # ERF_ABI_VERSION of include/erfnet_hip.h
+ABI_VERSION = 104                         # ERF_ABI_VERSION of include/erfnet_hip.h
 
 
 def lib():

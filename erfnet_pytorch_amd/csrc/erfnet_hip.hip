@@ -941,6 +941,20 @@ int run_pair_f32(const PairDesc &pd, int NC, int tile, hipStream_t st)
 // differ per convolution; K, Nout, ntaps, the pixel grid and the strides must agree.
 // `bias_taps`: bit t set = the bias row of tap t enters db (taps whose g pixels partition the
 // gradient tensor).
+// A run of non_bottleneck_1d blocks in backward (erf_batch_begin / erf_batch_pack / erf_batch_end): the
+// caller walks its blocks twice, each with a workspace of its own.  Pass 1 (collect) plans every block and
+// keeps its weight-packing descriptors; erf_batch_pack packs them all in one launch; pass 2 (run) plans
+// again (same workspace, same addresses), skips the packing and defers the slab reductions, which
+// erf_batch_end launches together.  Per thread: a run's backward is one autograd node on one thread.
+enum { BATCH_OFF = 0, BATCH_COLLECT = 1, BATCH_RUN = 2 };
+struct BatchCtx {
+    int mode = BATCH_OFF;
+    std::vector<PackDesc> packs;
+    struct Red { ReduceDesc r; long long nw; bool vec; };
+    std::vector<Red> reds;
+};
+static thread_local BatchCtx g_batch;
+
 int launch_reduce_batch(const WgradDesc *d, int n, float *const *dw, float *const *db, const int *woff,
                         int wsk, int wsn, unsigned bias_taps, hipStream_t st)
 {
@@ -962,6 +976,10 @@ int launch_reduce_batch(const WgradDesc *d, int n, float *const *dw, float *cons
     for (int i = 0; i < n && vec; ++i)
         vec = d[i].K == d[0].K && d[i].Nout == d[0].Nout && d[i].ntaps == d[0].ntaps && aligned16(d[i].partial) &&
               ((long long)d[i].ntaps * d[i].K * d[i].Nout + (long long)d[i].ntaps * d[i].Nout) % 4 == 0;
+    if (g_batch.mode == BATCH_RUN) {        // deferred: erf_batch_end launches it (the slabs stay where they are)
+        for (int i = 0; i < n; ++i) g_batch.reds.push_back(BatchCtx::Red{rb.r[i], nw, vec});
+        return 0;
+    }
     if (vec) {
         const int wblocks = (int)((nw + 127) / 128), bblocks = (d[0].Nout + 31) / 32;
         reduce_partials4_kernel<<<dim3((unsigned)(wblocks + bblocks), n, 1), 256, 0, st>>>(rb, wblocks);
@@ -1667,6 +1685,66 @@ int erf_set_option(int option, int value)
 const char *erf_last_error(void) { return g_err; }
 unsigned long long erf_launch_count(void) { return g_launches.load(); }
 
+int erf_batch_begin(void)
+{
+    if (g_batch.mode != BATCH_OFF) return fail("erf_batch_begin: a batch is already open on this thread");
+    g_batch.packs.clear();
+    g_batch.reds.clear();
+    g_batch.mode = BATCH_COLLECT;
+    return 0;
+}
+int erf_batch_pack(void *stream)
+{
+    if (g_batch.mode != BATCH_COLLECT) return fail("erf_batch_pack: no batch is collecting on this thread");
+    g_batch.mode = BATCH_OFF;       // (launch_pack itself is the ordinary path)
+    const int rc = g_batch.packs.empty() ? 0 : launch_pack(g_batch.packs.data(), (int)g_batch.packs.size(), (hipStream_t)stream);
+    g_batch.packs.clear();
+    if (rc) return 1;
+    g_batch.mode = BATCH_RUN;
+    return 0;
+}
+int erf_batch_end(void *stream)
+{
+    if (g_batch.mode != BATCH_RUN) return fail("erf_batch_end: no batch is running on this thread");
+    g_batch.mode = BATCH_OFF;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<BatchCtx::Red> reds;
+    reds.swap(g_batch.reds);
+    // runs of equal geometry (the blocks of a run are alike) go into one launch each, in the order deferred
+    for (size_t i = 0; i < reds.size();) {
+        const ReduceDesc &a = reds[i].r;
+        size_t j = i + 1;
+        while (j < reds.size() && j - i < (reds[i].vec ? (size_t)ERF_REDUCE_WIDE : (size_t)ERF_WGRAD_BATCH) &&
+               reds[j].vec == reds[i].vec && reds[j].nw == reds[i].nw && reds[j].r.Nout == a.Nout && reds[j].r.K == a.K &&
+               reds[j].r.kside == a.kside)
+            ++j;
+        const int n = (int)(j - i);
+        if (reds[i].vec) {
+            ReduceBatchWide wb;
+            memset(&wb, 0, sizeof(wb));
+            for (int k = 0; k < n; ++k) wb.r[k] = reds[i + k].r;
+            const int wblocks = (int)((reds[i].nw + 127) / 128), bblocks = ((a.kside ? a.K : a.Nout) + 31) / 32;
+            reduce_partials4_wide_kernel<<<dim3((unsigned)(wblocks + bblocks), n, 1), 256, 0, st>>>(wb, wblocks);
+            CHECK_LAUNCH("reduce_partials4_wide_kernel");
+        } else {
+            ReduceBatch rb;
+            memset(&rb, 0, sizeof(rb));
+            for (int k = 0; k < n; ++k) rb.r[k] = reds[i + k].r;
+            const long long tot = reds[i].nw + (a.kside ? a.K : a.Nout);
+            reduce_partials_kernel<<<dim3((unsigned)((tot + 31) / 32), n, 1), 256, 0, st>>>(rb);
+            CHECK_LAUNCH("reduce_partials_kernel");
+        }
+        i = j;
+    }
+    return 0;
+}
+void erf_batch_abort(void)
+{
+    g_batch.mode = BATCH_OFF;
+    g_batch.packs.clear();
+    g_batch.reds.clear();
+}
+
 size_t erf_workspace_bytes(long long n_pixels, int max_c)
 {
     // six gradient/activation temporaries + weight-gradient slabs + BatchNorm sums + slack
@@ -2253,7 +2331,11 @@ static int nb1d_backward_impl(int dt, const void *x, const float *const w[4], co
         if (plan_pair(d[1], d[0], true, ar, two, pd10)) return 1;
         pk[1] = two[0]; pk[0] = two[1];
     } else if (plan_igemm(d[1], ar, pk[1]) || plan_igemm(d[0], ar, pk[0])) return 1;
-    if (launch_pack(pk, 4, st)) return 1;
+    if (g_batch.mode == BATCH_COLLECT) {    // first pass over a run: nothing has been launched yet
+        g_batch.packs.insert(g_batch.packs.end(), pk, pk + 4);
+        return 0;
+    }
+    if (g_batch.mode != BATCH_RUN && launch_pack(pk, 4, st)) return 1;
     if (bits) {     // masks given as bits serve the launches of the rolling kernel (t1, t2, t3, x -> d[1], d[2], d[3], d[0])
         const int slot[4] = {3, 0, 1, 2};
         const bool own[4] = {!pair10, !pair10, !pair32, !pair32};

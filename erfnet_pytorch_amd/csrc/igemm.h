@@ -555,9 +555,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceBatch 
 // order (slabs g, g+8, ... of a group one after the other, then the eight groups), so the results
 // are bit-identical.  Blocks [0, wblocks) cover the weight part (128 elements each), the blocks
 // behind them the bias elements with the scalar code.
-__global__ __launch_bounds__(256) void reduce_partials4_kernel(const ReduceBatch batch, int wblocks)
+__device__ __forceinline__ void reduce_partials4_body(const ReduceDesc &d, int wblocks)
 {
-    const ReduceDesc &d = batch.r[blockIdx.y];
     const long long nw = (long long)d.ntaps * d.K * d.Nout;
     const long long slab = nw + (long long)d.ntaps * d.Nout + d.tail;
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -613,4 +612,19 @@ __global__ __launch_bounds__(256) void reduce_partials4_kernel(const ReduceBatch
 #pragma unroll
     for (int k = 1; k < 8; ++k) tot += red[k][e];
     d.db[j] = tot;
+}
+
+__global__ __launch_bounds__(256) void reduce_partials4_kernel(const ReduceBatch batch, int wblocks)
+{
+    reduce_partials4_body(batch.r[blockIdx.y], wblocks);
+}
+
+// The reductions a run of blocks deferred (erf_batch_end): up to 32 slabs sets of one geometry per launch.
+#define ERF_REDUCE_WIDE 32
+struct ReduceBatchWide {
+    ReduceDesc r[ERF_REDUCE_WIDE];
+};
+__global__ __launch_bounds__(256) void reduce_partials4_wide_kernel(const ReduceBatchWide batch, int wblocks)
+{
+    reduce_partials4_body(batch.r[blockIdx.y], wblocks);
 }

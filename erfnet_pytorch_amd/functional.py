@@ -24,9 +24,10 @@ def _stream(t):
     return vp(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def _workspace(t, n_pixels, max_c):
-    """Scratch buffer for one call, cached per (device, stream); stream order keeps reuse safe."""
-    need = _lib.lib().erf_workspace_bytes(int(n_pixels), int(max_c))
+def _workspace(t, n_pixels, max_c, copies=1):
+    """Scratch buffer for one call, cached per (device, stream); stream order keeps reuse safe.
+    copies > 1: room for that many disjoint workspaces (:func:`_workspace_slice` bytes apart)."""
+    need = _workspace_slice(n_pixels, max_c) * int(copies)
     key = (t.device.index, torch.cuda.current_stream(t.device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < need:
@@ -35,6 +36,11 @@ def _workspace(t, n_pixels, max_c):
         buf = torch.empty(int(need * 1.25), dtype=torch.uint8, device=t.device)
         _workspaces[key] = buf
     return buf
+
+
+def _workspace_slice(n_pixels, max_c):
+    """Bytes of one call's workspace, rounded up to a multiple of 256."""
+    return (_lib.lib().erf_workspace_bytes(int(n_pixels), int(max_c)) + 255) // 256 * 256
 
 
 def _p(t):
@@ -419,6 +425,19 @@ def nb1d(x, weights, biases, dilated, bn1=None, bn2=None, bn_mode=0, drop_scale=
                                    drop_scale, dilated, bn_mode, momentum, eps, tok), tok)
 
 
+# The backward of a run of blocks batches the weight-packing and slab-reduction launches of its blocks
+# (erf_batch_begin / erf_batch_pack / erf_batch_end) unless ERFNET_NO_BATCH_BWD=1 (A/B runs); the results
+# are bit-identical either way.
+_BATCH_BWD = os.environ.get("ERFNET_NO_BATCH_BWD", "0") in ("", "0")
+
+
+def set_batch_backward(enabled):
+    """Turn the batched backward of :func:`nb1d_chain` on or off; returns the previous setting."""
+    global _BATCH_BWD
+    prev, _BATCH_BWD = _BATCH_BWD, bool(enabled)
+    return prev
+
+
 # The ReLU masks of a run of blocks travel to its backward as bit tensors (sign_bits of
 # erf_nb1d_block_t) unless ERFNET_NO_SIGN_BITS=1 (A/B runs); results are bit-identical either way.
 _SIGN_BITS = os.environ.get("ERFNET_NO_SIGN_BITS", "0") in ("", "0")
@@ -525,7 +544,10 @@ class _Nb1dChain(torch.autograd.Function):
         gy = _nhwc(gy, x0.dtype)
         last_flags = _bwd_flags(ctx, gy)
         grads = [None] * (nb * 12)
-        ws = _workspace(x0, n * h * wd, c)
+        batched = _BATCH_BWD and nb > 1
+        ws = _workspace(x0, n * h * wd, c, nb if batched else 1)
+        ws_slice = _workspace_slice(n * h * wd, c) if batched else ws.numel()
+        calls, delivered = [], []
         for i in reversed(range(nb)):
             (y, t1, p2, t2, t3, p4, w0, w1, w2, w3, g1, g2, sm1, si1, sm2, si2, ds, bits) = saved[1 + i * per:1 + (i + 1) * per]
             x = saved[1 + (i - 1) * per] if i else x0
@@ -552,19 +574,42 @@ class _Nb1dChain(torch.autograd.Function):
                 flags = _lib.BWD_GY_PREMASKED
             if i > 0 or ctx.in_token is not None:
                 flags |= _lib.BWD_MASK_DX
-            with _dev_ctx(x):
-                if any(b is not None for b in sb):
-                    _lib.check(_fn("erf_nb1d_backward_bits", x)(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
-                                                          dil, _p(y), _arr([t1, p2, t2, t3, p4]), _arr(sb), _p(gy),
-                                                          _p(dx), _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c,
-                                                          h, wd, flags, _p(ws), ws.numel(), _stream(x)))
-                else:
-                    _lib.check(_fn("erf_nb1d_backward", x)(_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds),
-                                                           dil, _p(y), _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx),
-                                                           _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts), n, c, h, wd,
-                                                           flags, _p(ws), ws.numel(), _stream(x)))
-            grads[i * 12:(i + 1) * 12] = _match_params(_deliver(tg), params)
+            # every block of a batched run works in a workspace slice of its own
+            wsp = vp(ws.data_ptr() + (nb - 1 - i) * ws_slice) if batched else _p(ws)
+            if any(b is not None for b in sb):
+                fn = _fn("erf_nb1d_backward_bits", x)
+                args = (_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds), dil, _p(y),
+                        _arr([t1, p2, t2, t3, p4]), _arr(sb), _p(gy), _p(dx), _arr(dws), _arr(dbs), _arr(dgs),
+                        _arr(dbts), n, c, h, wd, flags, wsp, ws_slice, _stream(x))
+            else:
+                fn = _fn("erf_nb1d_backward", x)
+                args = (_p(x), _arr([w0, w1, w2, w3]), bn1.ref(), bn2.ref(), _p(ds), dil, _p(y),
+                        _arr([t1, p2, t2, t3, p4]), _p(gy), _p(dx), _arr(dws), _arr(dbs), _arr(dgs), _arr(dbts),
+                        n, c, h, wd, flags, wsp, ws_slice, _stream(x))
+            if batched:
+                calls.append((fn, args, (bn1, bn2, dx, gy)))      # (the tuple keeps the operands alive)
+            else:
+                with _dev_ctx(x):
+                    _lib.check(fn(*args))
+            delivered.append((i, tg, params))
             gy = dx
+        if batched:
+            # two passes over the same calls: plan and collect the weight packs, pack them in one launch,
+            # run; the slab reductions of all blocks follow together
+            with _dev_ctx(x0):
+                _lib.check(lib.erf_batch_begin())
+                try:
+                    for fn, args, _ in calls:
+                        _lib.check(fn(*args))
+                    _lib.check(lib.erf_batch_pack(_stream(x0)))
+                    for fn, args, _ in calls:
+                        _lib.check(fn(*args))
+                    _lib.check(lib.erf_batch_end(_stream(x0)))
+                except BaseException:
+                    lib.erf_batch_abort()
+                    raise
+        for i, tg, params in delivered:
+            grads[i * 12:(i + 1) * 12] = _match_params(_deliver(tg), params)
         return (_hand_over(ctx, gy), None, None, *grads)
 
 

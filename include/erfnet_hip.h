@@ -50,13 +50,31 @@ typedef struct {
  * mismatch (struct layouts are part of the ABI: revision 101 added erf_bn_t::num_batches_tracked and
  * changed erf_nb1d_block_t's member types, 102 added ERF_OPT_X3_ROLL and the capture rule of
  * erf_cross_entropy_forward_static, 103 added erf_nb1d_block_t::sign_bits / sign_bits_written and
- * erf_nb1d_backward_bits). */
-#define ERF_ABI_VERSION 103
+ * erf_nb1d_backward_bits, 104 the erf_batch_* calls). */
+#define ERF_ABI_VERSION 104
 int erf_version(void);
 const char *erf_last_error(void);
 /* Number of kernel launches issued through this library by the calling process (tests use it to
  * prove the HIP path, not a fallback, produced a result). */
 unsigned long long erf_launch_count(void);
+
+/* Backward of a run of non_bottleneck_1d blocks (`for layer in self.layers`,
+ * train/net_classification.py:32-36,42-45, walked in reverse by autograd) with the small launches of
+ * its blocks batched: one weight-packing launch for the run instead of one per block, and the slab
+ * reductions of all its weight gradients together at the end.  Protocol, on one thread and one stream:
+ *   erf_batch_begin();
+ *   for every block, last to first:  erf_nb1d_backward*( ... )     plans only, launches nothing
+ *   erf_batch_pack(stream);
+ *   for every block, same order, SAME arguments:  erf_nb1d_backward*( ... )
+ *   erf_batch_end(stream);                                         the weight gradients are complete here
+ * Every block needs a workspace of its own (erf_workspace_bytes each, disjoint), unchanged between the
+ * two passes: its packed weights and gradient slabs live there until erf_batch_end.  Results are bit-
+ * identical to the unbatched calls.  erf_batch_abort() leaves the protocol after an error.  Only
+ * erf_nb1d_backward, erf_nb1d_backward_bits and their _bf16 forms may be called between begin and end. */
+int erf_batch_begin(void);
+int erf_batch_pack(void *stream);
+int erf_batch_end(void *stream);
+void erf_batch_abort(void);
 
 /* Tuning switches (no counterpart in the reference).  erf_set_option returns the previous value,
  * or -1 for an unknown option.  ERF_OPT_PAIR_FUSION (default 1; environment ERFNET_NO_PAIR=1 turns
