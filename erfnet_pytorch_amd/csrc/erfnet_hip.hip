@@ -2633,11 +2633,12 @@ static int outconv_ce_forward_impl(int dt, const void *x, const float *w, const 
     else if (ncls == 19) BY_DT(dt, (outconv_ce_fwd_kernel<T, 19><<<(unsigned)blocks, 256, 0, st>>>(d)));
     else BY_DT(dt, (outconv_ce_fwd_kernel<T, 0><<<(unsigned)blocks, 256, 0, st>>>(d)));
     CHECK_LAUNCH("outconv_ce_fwd_kernel");
-    ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
-    CHECK_LAUNCH("ce_reduce_kernel");
     if (counts) {
-        ce_count_sum_kernel<<<2 * ncls, 256, 0, st>>>(cpartial, (int)blocks, 2 * ncls, counts);
-        CHECK_LAUNCH("ce_count_sum_kernel");
+        ce_reduce_counts_kernel<<<1 + 2 * ncls, 256, 0, st>>>(partial, (int)blocks, stats, cpartial, 2 * ncls, counts);
+        CHECK_LAUNCH("ce_reduce_counts_kernel");
+    } else {
+        ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
+        CHECK_LAUNCH("ce_reduce_kernel");
     }
     return 0;
 }
@@ -2745,11 +2746,12 @@ static int cross_entropy_forward_impl(const float *logits, const long long *targ
     if (K <= CE_MAX_K) ce_fwd_kernel<true><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     else ce_fwd_kernel<false><<<(unsigned)blocks, CE_BLOCK, 0, st>>>(d);
     CHECK_LAUNCH("ce_fwd_kernel");
-    ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
-    CHECK_LAUNCH("ce_reduce_kernel");
     if (counts) {
-        ce_count_sum_kernel<<<2 * K, 256, 0, st>>>(cpartial, (int)blocks, 2 * K, counts);
-        CHECK_LAUNCH("ce_count_sum_kernel");
+        ce_reduce_counts_kernel<<<1 + 2 * K, 256, 0, st>>>(partial, (int)blocks, stats, cpartial, 2 * K, counts);
+        CHECK_LAUNCH("ce_reduce_counts_kernel");
+    } else {
+        ce_reduce_kernel<<<1, 256, 0, st>>>(partial, (int)blocks, stats);
+        CHECK_LAUNCH("ce_reduce_kernel");
     }
     return 0;
 }

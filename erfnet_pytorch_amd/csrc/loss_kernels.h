@@ -106,10 +106,9 @@ __global__ __launch_bounds__(CE_BLOCK) void ce_fwd_kernel(const CeDesc d)
 }
 
 // counts[j] = sum over blocks of cpartial[block][j], j < 2K: one block per column, exact integers.
-__global__ __launch_bounds__(256) void ce_count_sum_kernel(const unsigned *cpartial, int nblocks, int J, long long *counts)
+__device__ __forceinline__ void ce_count_sum_body(const unsigned *cpartial, int nblocks, int J, long long *counts, int j)
 {
     __shared__ long long red[256];
-    const int j = blockIdx.x;
     long long s = 0;
     for (int i = threadIdx.x; i < nblocks; i += 256) s += cpartial[(long long)i * J + j];
     red[threadIdx.x] = s;
@@ -120,10 +119,14 @@ __global__ __launch_bounds__(256) void ce_count_sum_kernel(const unsigned *cpart
     }
     if (threadIdx.x == 0) counts[j] = red[0];
 }
+__global__ __launch_bounds__(256) void ce_count_sum_kernel(const unsigned *cpartial, int nblocks, int J, long long *counts)
+{
+    ce_count_sum_body(cpartial, nblocks, J, counts, blockIdx.x);
+}
 
 // stats[0] = mean loss, stats[1] = number of labelled pixels.  One block, fixed summation order
 // (double accumulators: tens of thousands of partials).
-__global__ __launch_bounds__(256) void ce_reduce_kernel(const float *partial, int nblocks, float *stats)
+__device__ __forceinline__ void ce_reduce_body(const float *partial, int nblocks, float *stats)
 {
     __shared__ double red[2][256];
     double a = 0.0, b = 0.0;
@@ -145,6 +148,18 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float *partial, in
         stats[0] = (float)(red[0][0] / red[1][0]);     // 0/0 = NaN when nothing is labelled, as in torch
         stats[1] = (float)red[1][0];
     }
+}
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float *partial, int nblocks, float *stats)
+{
+    ce_reduce_body(partial, nblocks, stats);
+}
+// Both reductions behind a loss forward that also counts (accuracy metrics): block 0 the loss, blocks
+// 1 .. J the count columns — the same code, one launch.
+__global__ __launch_bounds__(256) void ce_reduce_counts_kernel(const float *partial, int nblocks, float *stats,
+                                                               const unsigned *cpartial, int J, long long *counts)
+{
+    if (blockIdx.x == 0) ce_reduce_body(partial, nblocks, stats);
+    else ce_count_sum_body(cpartial, nblocks, J, counts, (int)blockIdx.x - 1);
 }
 
 // Output convolution + CrossEntropyLoss in one pass, for the training loop whose only use of the logits

@@ -121,8 +121,7 @@ class GradientReducer:
         ``defer=True``: no all-reduce is launched from inside backward; ``finish()`` launches them all.
         Needed when the step calls ``backward()`` more than once or shares weights between layers."""
         self._defer = bool(defer)
-        for flat, _ in self._buckets:
-            flat.zero_()
+        torch._foreach_zero_([flat for flat, _ in self._buckets])      # (one launch for all buckets)
         self._pending = {i: len(ps) for i, (_, ps) in enumerate(self._buckets)}
         self._work = []
         self._seen = set()

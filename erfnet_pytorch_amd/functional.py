@@ -877,9 +877,14 @@ def _materialize_logits(t):
 class _LossToken:
     __slots__ = ("pending", "zero")
 
+    _zeros = {}         # one read-only zero scalar per device (a fill launch per forward otherwise)
+
     def __init__(self, device):
         self.pending = []
-        self.zero = torch.zeros((), dtype=torch.float32, device=device)
+        z = _LossToken._zeros.get(device)
+        if z is None:
+            z = _LossToken._zeros[device] = torch.zeros((), dtype=torch.float32, device=device)
+        self.zero = z
 
     def is_stand_in(self, g):
         return g.data_ptr() == self.zero.data_ptr() and all(s == 0 for s in g.stride())

@@ -63,11 +63,10 @@ for name, n in sorted(kern.items(), key=lambda kv: -ktime[kv[0]]):
 print("\ntorch-side ops with GPU work (per step):")
 groups = collections.Counter()
 for e in events:
-    if e.device_type != torch.autograd.DeviceType.CPU or not e.name.startswith("aten::"):
+    if e.device_type != torch.autograd.DeviceType.CPU:
         continue
-    if not any(k.device_type == torch.autograd.DeviceType.CUDA for k in getattr(e, "kernels", [])) and not getattr(e, "kernels", None):
-        continue
-    if not e.kernels:
+    if e.name not in ("aten::zero_", "aten::fill_", "aten::zeros", "aten::copy_", "aten::cat", "aten::clone",
+                      "aten::_to_copy", "aten::add_", "aten::mul_", "aten::div_", "aten::sum", "aten::mean"):
         continue
     frame = ""
     for f in (e.stack or []):
