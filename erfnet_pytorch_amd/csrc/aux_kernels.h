@@ -236,8 +236,18 @@ __global__ __launch_bounds__(256) void reduce_flat_kernel(const float *partial, 
     const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + e;
     float s = 0.0f;
-    if (idx < nw + nb)
-        for (int i = g; i < nsplit; i += 8) s += partial[(long long)i * (nw + nb) + idx];
+    if (idx < nw + nb) {
+        // (eight slabs per trip, requested together, added in slab order: see outconv_wreduce_kernel)
+        int i = g;
+        for (; i + 56 < nsplit; i += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(i + 8 * u) * (nw + nb) + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < nsplit; i += 8) s += partial[(long long)i * (nw + nb) + idx];
+    }
     red[g][e] = s;
     __syncthreads();
     if (g != 0 || idx >= nw + nb) return;
@@ -1075,10 +1085,32 @@ __global__ __launch_bounds__(256) void outconv_wreduce_kernel(const float *parti
     const int idx = blockIdx.x * 32 + e;
     float s = 0.0f;
     if (idx < nw) {
-        for (int i = g; i < nsplit; i += 8) s += partial[(long long)i * slab + idx];
+        // eight slabs of this group per trip, all requested before the first addition (added in the same
+        // order as one by one: the sum is bit-identical, the loads no longer wait for each other)
+        int i = g;
+        for (; i + 56 < nsplit; i += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(i + 8 * u) * slab + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; i < nsplit; i += 8) s += partial[(long long)i * slab + idx];
     } else if (idx < nw + ncls) {
         const int o = idx - nw;
-        for (int i = g; i < nsplit; i += 8)
+        int i = g;
+        for (; i + 24 < nsplit; i += 32) {      // four slabs per trip (sixteen loads), same order of additions
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) v[u][ab] = partial[(long long)(i + 8 * u) * slab + nw + o * 4 + ab];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) s += v[u][ab];
+        }
+        for (; i < nsplit; i += 8)
             for (int ab = 0; ab < 4; ++ab) s += partial[(long long)i * slab + nw + o * 4 + ab];
     }
     red[g][e] = s;

@@ -507,6 +507,22 @@ struct ReduceBatch {
     ReduceDesc r[ERF_WGRAD_BATCH];
 };
 
+// s + partial[g][off] + partial[g+8][off] + ... in that order, eight slabs requested per trip (added one
+// by one the loads wait for each other: 64 dependent round trips at 512 slabs).
+__device__ __forceinline__ float reduce_column8(const float *partial, long long slab, long long off, int g, int nsplit, float s)
+{
+    int i = g;
+    for (; i + 56 < nsplit; i += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(long long)(i + 8 * u) * slab + off];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < nsplit; i += 8) s += partial[(long long)i * slab + off];
+    return s;
+}
+
 // Block = 32 consecutive slab elements x 8 slab groups: thread (g, e) sums slabs g, g+8, ... of
 // element e, the 8 group sums are then added in a fixed order through LDS.
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceBatch batch)
@@ -520,16 +536,16 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const ReduceBatch 
     const long long idx = (long long)blockIdx.x * 32 + e;
     float s = 0.0f;
     if (idx < nw) {
-        for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + idx];
+        s = reduce_column8(d.partial, slab, idx, g, d.nsplit, s);
     } else if (idx < nw + nb) {
         const int j = (int)(idx - nw);
         if (d.kside) {
             const long long off = nw + (long long)d.ntaps * d.Nout + j;
-            for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + off];
+            s = reduce_column8(d.partial, slab, off, g, d.nsplit, s);
         } else {
             for (int t = 0; t < d.ntaps; ++t) {
                 if (!((d.bias_taps >> t) & 1u)) continue;
-                for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + nw + (long long)t * d.Nout + j];
+                s = reduce_column8(d.partial, slab, nw + (long long)t * d.Nout + j, g, d.nsplit, s);
             }
         }
     }
@@ -597,11 +613,11 @@ __device__ __forceinline__ void reduce_partials4_body(const ReduceDesc &d, int w
     if (j < nb) {
         if (d.kside) {
             const long long off = nw + (long long)d.ntaps * d.Nout + j;
-            for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + off];
+            s = reduce_column8(d.partial, slab, off, g, d.nsplit, s);
         } else {
             for (int t = 0; t < d.ntaps; ++t) {
                 if (!((d.bias_taps >> t) & 1u)) continue;
-                for (int i = g; i < d.nsplit; i += 8) s += d.partial[(long long)i * slab + nw + (long long)t * d.Nout + j];
+                s = reduce_column8(d.partial, slab, nw + (long long)t * d.Nout + j, g, d.nsplit, s);
             }
         }
     }
