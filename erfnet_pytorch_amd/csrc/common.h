@@ -90,6 +90,7 @@ struct IgemmDesc {
     int Npad;          // padded column count of wp (multiple of the block's BN)
     int cfg;           // host side: tile configuration chosen by plan_igemm
     int vec_ok;        // in_C, in_coff, K all multiples of 4 and `in` 16-byte aligned
+    int x3_plane;      // igemm_x3_kernel: bf16 elements per plane of the split packed weights
     double *bn_partial;    // host side, may be null: line_x3_kernel leaves per-block column sums of the output
                            // and of its squares here ([blocks][2 * Nout]: train-mode BatchNorm statistics)
 };

@@ -11,6 +11,7 @@
 #include "line_x3.h"
 #include "line_x3r.h"
 #include "igemm_bf16.h"
+#include "igemm_x3.h"
 #include "wgrad_line.h"
 #include "wgrad_line_bf16.h"
 #include "wgrad_mm.h"
@@ -442,6 +443,32 @@ bool igemm_bf16_ok(const IgemmDesc &d)
     return true;
 }
 
+// fp32 tensors with split operands on the bf16 MFMA (igemm_x3_kernel), tiles {pixels, 64 channels}.
+// Follows the split-arithmetic switch of the line kernels; ERFNET_NO_IGEMM_X3=1 keeps these shapes on the
+// fp32 MFMA (experiments).
+const int kCfgX3 = 300;
+bool igemm_x3_ok(const IgemmDesc &d)
+{
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("ERFNET_NO_IGEMM_X3"); off = (e && atoi(e)) ? 1 : 0; }
+    if (d.dt || off || x3_mode() == 0) return false;
+    // not the 3-tap 1-D convolutions of a non_bottleneck_1d: where the line kernels leave one of those to the
+    // generic path, the fused fp32 pair may take its neighbour, and a run of blocks has to equal its blocks
+    // called one by one bit for bit
+    if (d.ss == 1 && d.os == 1 && d.ngroups == 1 && d.gntaps[0] == 3) return false;
+    if (d.K % 8 || d.in_C % 4 || d.in_coff % 4 || !aligned16(d.in)) return false;
+    if (d.Nout % 4 || d.out_C % 4 || d.out_coff % 4 || !aligned16(d.out)) return false;
+    if (d.epi.res && (d.epi.res_C % 4 || d.epi.res_coff % 4 || !aligned16(d.epi.res))) return false;
+    if (d.epi.mask && (d.epi.mask_C % 4 || d.epi.mask_coff % 4 || !aligned16(d.epi.mask))) return false;
+    if (d.epi.nscale && !aligned16(d.epi.nscale)) return false;
+    const long long lim = 1LL << 29;
+    const long long pin = (long long)d.N * d.in_H * d.in_W, pout = (long long)d.N * d.out_H * d.out_W;
+    if (pin * d.in_C >= lim || pout * d.out_C >= lim) return false;
+    if (d.epi.res && pout * d.epi.res_C >= lim) return false;
+    if (d.epi.mask && pout * d.epi.mask_C >= lim) return false;
+    return true;
+}
+
 // Validate, choose the tile, reserve the packed-weight buffer and describe the packing job.
 int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
 {
@@ -492,6 +519,26 @@ int plan_igemm(IgemmDesc &d, Arena &ar, PackDesc &pk)
         d.cfg = kCfgStream16;
         d.Npad = 16;
         memset(&pk, 0, sizeof(pk));
+        return 0;
+    }
+    if (igemm_x3_ok(d)) {           // fp32 tensors, split operands on the bf16 MFMA: three packed bf16 planes
+        const long long b128 = (M + 127) / 128, b64 = (M + 63) / 64;
+        const long long c128 = ((b128 + 511) / 512) * 128, c64 = ((b64 + 511) / 512) * 64;   // two blocks per CU
+        d.cfg = kCfgX3 + (c64 < c128 ? 1 : 0);
+        d.Npad = (d.Nout + 63) / 64 * 64;
+        int ntaps = 0;
+        for (int g = 0; g < d.ngroups; ++g) ntaps = d.gtap0[g] + d.gntaps[g] > ntaps ? d.gtap0[g] + d.gntaps[g] : ntaps;
+        const int kchunks = (d.K + 31) / 32;
+        const size_t n = (size_t)ntaps * kchunks * d.Npad * 32;
+        void *wp = ar.take(3 * n * sizeof(bf16_t));
+        if (!wp) return fail("igemm: workspace too small for the split packed weights (%zu bf16)", 3 * n);
+        d.wp = wp;
+        d.x3_plane = (int)n;
+        memset(&pk, 0, sizeof(pk));
+        pk.w = d.w; pk.wp = (float *)wp; pk.bf16 = 3;
+        pk.ntaps = ntaps; pk.K = d.K; pk.Nout = d.Nout; pk.Npad = d.Npad; pk.wsk = d.wsk; pk.wsn = d.wsn;
+        pk.kc = 32;
+        for (int t = 0; t < ERF_MAX_TAPS; ++t) pk.woff[t] = d.woff[t];
         return 0;
     }
     if (igemm_bf16_ok(d)) {         // bf16 tensors: bf16 MFMA, bf16 packed weights
@@ -658,6 +705,17 @@ int run_igemm_t(const IgemmDesc &d, hipStream_t st)
         else conv16_kernel<T, 3, 4><<<(unsigned)((M + 255) / 256), 256, 0, st>>>(d);
         CHECK_LAUNCH("conv16_kernel");
         return 0;
+    }
+    if (d.cfg >= kCfgX3) {
+        if constexpr (std::is_same<T, float>::value) {
+            const int bm = d.cfg == kCfgX3 ? 128 : 64;
+            dim3 grid((unsigned)((M + bm - 1) / bm), d.Npad / 64, d.ngroups);
+            if (bm == 128) igemm_x3_kernel<2, 1, 2, 2, 2><<<grid, 256, 0, st>>>(d);
+            else igemm_x3_kernel<1, 1, 2, 2, 2><<<grid, 256, 0, st>>>(d);
+            CHECK_LAUNCH("igemm_x3_kernel");
+            return 0;
+        }
+        return fail("igemm: split-operand plan on a bf16 tensor");
     }
     if (d.cfg >= kCfgBf16) {
         const TileCfg c = kCfgB[d.cfg - kCfgBf16];

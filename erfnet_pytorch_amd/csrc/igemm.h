@@ -41,7 +41,8 @@ struct PackDesc {
     int woff[ERF_MAX_TAPS];
     int line;                                  // 1 = bf16 MFMA fragments for the line kernel (K = Nout = 64 / 128) into lwp; 2 = three split planes
     bf16_t *lwp;
-    int bf16;                                  // 1 = wp receives bf16 values (igemm_bf16_kernel), same order
+    int bf16;                                  // 1 = wp receives bf16 values (igemm_bf16_kernel), same order; 3 = three
+                                               // bf16 planes wp[plane][...] of the split value (igemm_x3_kernel)
 };
 #define ERF_PACK_BATCH 32
 struct PackBatch {
@@ -63,7 +64,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackBatch b)
         const int k = kc * KC + kk;
         float v = 0.0f;
         if (k < d.K && j < d.Nout) v = d.w[d.woff[t] + (long long)k * d.wsk + (long long)j * d.wsn];
-        if (d.bf16) reinterpret_cast<bf16_t *>(d.wp)[idx] = f32_to_bf16(v);
+        if (d.bf16 == 3) {          // v = hi + mid + lo exactly (as line_pack_kernel splits)
+            bf16_t *o = reinterpret_cast<bf16_t *>(d.wp);
+            const bf16_t hi = f32_to_bf16(v);
+            const float r1 = v - bf16_to_f32(hi);
+            const bf16_t mid = f32_to_bf16(r1);
+            o[idx] = hi;
+            o[(long long)total + idx] = mid;
+            o[2LL * total + idx] = f32_to_bf16(r1 - bf16_to_f32(mid));
+        } else if (d.bf16) reinterpret_cast<bf16_t *>(d.wp)[idx] = f32_to_bf16(v);
         else d.wp[idx] = v;
     }
 }

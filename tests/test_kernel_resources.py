@@ -27,6 +27,7 @@ BUDGET = {
     "void wgrad_line_bf16_kernel<64, 1, 1, 2, 2, 3>(": (3, 0),
     "void conv16_rows_kernel<4, 4, true>(": (3, 0),
     "void conv16_bf16_rows_kernel<8, 2, true>(": (2, 0),
+    "void igemm_x3_kernel<2, 1, 2, 2, 2>(": (2, 0),
     "void first_down_fwd_kernel<float>(": (4, 0),
     "void first_down_fwd_kernel<unsigned short>(": (4, 0),
 }

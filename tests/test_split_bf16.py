@@ -261,3 +261,51 @@ def test_relu_masks_as_bits_bf16(C_, N, H, W, dils):
     """The same on bf16 tensors, where the paired launches write and read the bits (ragged tiles and
     single-block runs included)."""
     _run_bits_case(torch.bfloat16, C_, N, H, W, dils, 0, _expected_bits_bf16(C_, H, W, dils, 0))
+
+
+@pytest.mark.parametrize("kind,cin,cout,N,H,W", [("down", 16, 64, 2, 40, 72), ("down", 64, 128, 3, 34, 50),
+                                                 ("up", 128, 64, 2, 17, 40), ("conv3x3", 64, 20, 1, 20, 36)])
+def test_generic_convolutions_split_against_float64(kind, cin, cout, N, H, W):
+    """The stride-2 layers (and the other generic convolutions) of fp32 tensors on igemm_x3_kernel: the output
+    against float64 within 4e-6 of its scale and no less accurate than the fp32-MFMA kernel (split arithmetic
+    switched off) by more than a small factor; the input gradient within 1e-5 relative L2."""
+    from erfnet_pytorch_amd import _lib, functional as hipf
+    import golden_util as gu
+    wshape = {"down": (cout - cin, cin, 3, 3), "up": (cin, cout, 3, 3), "conv3x3": (cout, cin, 3, 3)}[kind]
+    nb = wshape[1] if kind == "up" else wshape[0]
+    w = torch.from_numpy(gu.det_normal("gx3.w." + kind, wshape) * (0.5 / np.sqrt(9 * cin))).to(DEV)
+    b = torch.from_numpy(0.1 * gu.det_normal("gx3.b." + kind, (nb,))).to(DEV)
+    x = torch.from_numpy(np.maximum(gu.det_normal("gx3.x." + kind, (N, cin, H, W)), 0)).to(DEV)
+
+    def composite(xx, ww, bb, hip):
+        if kind == "down":
+            return hipf.downsampler(xx, ww, bb) if hip else torch.relu(torch.cat(
+                [F.conv2d(xx, ww, bb, stride=2, padding=1), F.max_pool2d(xx, 2, 2)], 1))
+        if kind == "up":
+            return hipf.upsampler(xx, ww, bb) if hip else torch.relu(
+                F.conv_transpose2d(xx, ww, bb, stride=2, padding=1, output_padding=1))
+        return hipf.conv2d(xx, ww, bb) if hip else F.conv2d(xx, ww, bb, padding=1)
+
+    x64 = x.double().requires_grad_(True)
+    ref = composite(x64, w.double(), b.double(), False)
+    gy = torch.from_numpy(gu.det_normal("gx3.gy." + kind, tuple(ref.shape))).to(DEV)
+    ref.backward(gy.double())
+    scale = ref.detach().abs().max().item()
+
+    def run():
+        xx = x.clone().requires_grad_(True)
+        y = composite(xx, w, b, True)
+        y.backward(gy)
+        e_y = (y.detach().double() - ref.detach()).abs().max().item() / scale
+        e_g = ((xx.grad.double() - x64.grad).norm() / x64.grad.norm()).item()
+        return e_y, e_g
+
+    e_split, g_split = run()
+    prev = _lib.set_option(_lib.OPT_SPLIT_BF16, 0)
+    try:
+        e_fp32, g_fp32 = run()
+    finally:
+        _lib.set_option(_lib.OPT_SPLIT_BF16, prev)
+    assert e_split <= 4e-6, (e_split, e_fp32)
+    assert e_split <= 3 * e_fp32 + 1e-7, (e_split, e_fp32)
+    assert g_split <= 1e-5, (g_split, g_fp32)
