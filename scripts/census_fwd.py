@@ -1,5 +1,6 @@
+"""Census of the GPU launches of one full-resolution bf16 inference forward (erfnet_nobn.ERFNet(19), 1x3x1024x2048)."""
 import collections, os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from erfnet_pytorch_amd import erfnet_nobn
 from torch.profiler import ProfilerActivity, profile
 net = erfnet_nobn.ERFNet(19).to("cuda:0").eval()

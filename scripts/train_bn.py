@@ -22,5 +22,6 @@ def step():
 for _ in range(4): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10): l = step()
+t_issue = (time.perf_counter() - t0) / 10
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-print(f"ERFNet(20) BN-train + dropout: {dt*1e3:.2f} ms/step  {B/dt:.1f} images/s  loss {float(l):.4f}")
+print(f"ERFNet(20) BN-train + dropout: {dt*1e3:.2f} ms/step  {B/dt:.1f} images/s  loss {float(l):.4f}  (host issue time {t_issue*1e3:.2f} ms/step)")
