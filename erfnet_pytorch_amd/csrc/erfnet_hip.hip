@@ -1319,7 +1319,10 @@ int launch_up16_fwd(const IgemmDesc &d, hipStream_t st)
     const long long M = (long long)d.N * d.GH * d.GW;
     if (M == 0) return 0;
     long long blocks = (M + 63) / 64;             // one 16-position tile per wave at least
-    if (blocks > 768) blocks = 768;               // three resident blocks per CU share the weight fill
+    // as many blocks as are resident at once (bf16: three per CU; fp32: two, its waves hold 200+
+    // registers): every block pays the weight fill, so further blocks cost more than they hide
+    const long long cap = d.dt ? 768 : 512;
+    if (blocks > cap) blocks = cap;
     if (d.dt && d.in_C % 8 == 0 && d.in_coff % 8 == 0 && d.K % 16 == 0 && d.K <= 64) {     // bf16 tensors: bf16 MFMA
         switch (d.K / 16) {
         case 1: up16_fwd_bf16_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(d); break;

@@ -32,9 +32,23 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
     __shared__ __attribute__((aligned(16))) float Wl[9 * KQ * 256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    for (int idx = tid; idx < 9 * KQ * 256; idx += 256) {
-        const int kk = idx & 15, j = (idx >> 4) & 15, q = (idx >> 8) % KQ, t = idx / (KQ * 256);
-        Wl[idx] = d.w[t + (long long)(16 * q + kk) * d.wsk + (long long)j * d.wsn];
+    if (d.wsn == 9 && d.wsk == 144 && ((unsigned long long)d.w & 15) == 0) {
+        // torch's dense [K][16][3][3] weight: read in memory order (16-byte loads, a wave covers 1 KiB
+        // contiguous) and scattered into the LDS image — the gather below costs a block 36 loads per
+        // thread with one element per cache-line piece
+        for (int v4 = tid; v4 < 9 * KQ * 64; v4 += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(d.w + 4 * v4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = 4 * v4 + c, k = e / 144, rem = e - k * 144, j = rem / 9, t = rem - j * 9;
+                Wl[((t * KQ + (k >> 4)) * 16 + j) * 16 + (k & 15)] = v[c];
+            }
+        }
+    } else {
+        for (int idx = tid; idx < 9 * KQ * 256; idx += 256) {
+            const int kk = idx & 15, j = (idx >> 4) & 15, q = (idx >> 8) % KQ, t = idx / (KQ * 256);
+            Wl[idx] = d.w[t + (long long)(16 * q + kk) * d.wsk + (long long)j * d.wsn];
+        }
     }
     __syncthreads();
 
@@ -63,37 +77,65 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
         }
     }
 
+    // A wave walks its tiles in steps of 16 coarse channels (q): the four source loads of the NEXT step
+    // (the next tile's first one behind a tile's last) are requested before the 36 MFMAs of the current
+    // one, and the residual / mask of a tile before its last step — one round trip per tile and three or
+    // four waves per SIMD left the matrix pipe idle two thirds of the time.
+    struct Geo { unsigned n, y, x; bool valid; };
     const unsigned ntiles = (M + 15) / 16;
-    for (unsigned tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    auto geo_of = [&](unsigned tile) __attribute__((always_inline)) {
+        Geo t;
         const unsigned p = tile * 16 + i;
-        const bool valid = p < M;
-        const unsigned pp = valid ? p : 0;
-        const unsigned n = pp / HW, rem = pp - n * HW;
-        const unsigned y = rem / W, x = rem - y * W;
-        f32x4 xs[4][KQ];
+        t.valid = tile < ntiles && p < M;
+        const unsigned pp = t.valid ? p : 0;
+        t.n = pp / HW;
+        const unsigned rem = pp - t.n * HW;
+        t.y = rem / W; t.x = rem - t.y * W;
+        return t;
+    };
+    auto src_offs = [&](const Geo &t, unsigned (&off)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const unsigned ys = y + (s >> 1), xx = x + (s & 1);
-            const bool ok = valid && ys < H && xx < W;
-            const unsigned off = ((n * H + ys) * W + xx) * d.in_C + d.in_coff + 4 * g;
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) xs[s][q] = Act<T>::load4(r_in, ok ? off + q * 16u : ERF_OOB);
+            const unsigned ys = t.y + (s >> 1), xx = t.x + (s & 1);
+            const bool ok = t.valid && ys < H && xx < W;
+            off[s] = ok ? ((t.n * H + ys) * W + xx) * d.in_C + d.in_coff + 4 * g : ERF_OOB;
         }
-        // epilogue operands of the four fine pixels
+    };
+    auto load_q = [&](const unsigned (&off)[4], int q, f32x4 (&xq)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) xq[s] = Act<T>::load4(r_in, off[s] + q * 16u);      // (the out-of-range flag survives the addition)
+    };
+    constexpr int NB = KQ == 1 ? 1 : (KQ % 2 == 0 ? 2 : 3);       // step q of a tile sits in buffer q % NB; KQ % NB == 0
+    const unsigned stride = gridDim.x * 4;
+    unsigned tile = blockIdx.x * 4 + wave;
+    Geo tc = geo_of(tile);
+    unsigned oc[4];
+    src_offs(tc, oc);
+    f32x4 xq[NB][4];
+    if (NB > 1) load_q(oc, 0, xq[0]);
+    for (; tile < ntiles; tile += stride) {
+        const Geo tn = geo_of(tile + stride);
+        unsigned on[4];
+        src_offs(tn, on);
         unsigned ooff[4];
         f32x4 rres[4], rmask[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
-            ooff[c] = valid ? (px * d.out_C + d.out_coff + 4 * g) : ERF_OOB;
-            rres[c] = Act<T>::load4(r_res, valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) : ERF_OOB);
-            rmask[c] = Act<T>::load4(r_mask, valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) : ERF_OOB);
-        }
         f32x4 acc[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int q = 0; q < KQ; ++q) {
+            if (NB == 1) load_q(oc, 0, xq[0]);
+            else if (q + 1 < KQ) load_q(oc, q + 1, xq[(q + 1) % NB]);
+            else load_q(on, 0, xq[0]);
+            if (q == KQ - 1) {      // epilogue operands of the four fine pixels
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned px = (tc.n * 2 * H + 2 * tc.y + (c >> 1)) * 2 * W + 2 * tc.x + (c & 1);
+                    ooff[c] = tc.valid ? (px * d.out_C + d.out_coff + 4 * g) : ERF_OOB;
+                    rres[c] = Act<T>::load4(r_res, tc.valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) : ERF_OOB);
+                    rmask[c] = Act<T>::load4(r_mask, tc.valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) : ERF_OOB);
+                }
+            }
             f32x4 wf[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t)
@@ -103,7 +145,7 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int t = 0; t < 9; ++t)
-                    acc[S16_CLASS(t)] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][m], xs[S16_SRC(t)][q][m],
+                    acc[S16_CLASS(t)] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t][m], xq[q % NB][S16_SRC(t)][m],
                                                                              acc[S16_CLASS(t)], 0, 0, 0);
         }
 #pragma unroll
@@ -117,6 +159,9 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
             }
             Act<T>::store4(r_out, ooff[c], v);
         }
+        tc = tn;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) oc[s] = on[s];
     }
 }
 
@@ -132,10 +177,27 @@ __global__ __launch_bounds__(256) void up16_fwd_bf16_kernel(const IgemmDesc d)
     __shared__ __attribute__((aligned(16))) bf16_t Wl[9 * NK * 16 * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    for (int idx = tid; idx < 9 * NK * 16 * 32; idx += 256) {
-        const int e = idx & 31, j = (idx >> 5) & 15, kk = (idx >> 9) % NK, t = idx / (NK * 512);
-        const int k = kk * 32 + e;
-        Wl[idx] = f32_to_bf16(k < 16 * KQ ? d.w[t + (long long)k * d.wsk + (long long)j * d.wsn] : 0.0f);
+    if (d.wsn == 9 && d.wsk == 144 && ((unsigned long long)d.w & 15) == 0) {
+        // (dense [K][16][3][3] weight read in memory order, as in up16_fwd_kernel)
+        if (KQ & 1) {       // the upper half of the last 32-channel group has no weights: zeros
+            for (int v4 = tid; v4 < 9 * NK * 16 * 4; v4 += 256)
+                *reinterpret_cast<u32x4 *>(&Wl[8 * v4]) = u32x4{0u, 0u, 0u, 0u};
+            __syncthreads();
+        }
+        for (int v4 = tid; v4 < 9 * KQ * 64; v4 += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(d.w + 4 * v4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int e = 4 * v4 + c, k = e / 144, rem = e - k * 144, j = rem / 9, t = rem - j * 9;
+                Wl[((t * NK + (k >> 5)) * 16 + j) * 32 + (k & 31)] = f32_to_bf16(v[c]);
+            }
+        }
+    } else {
+        for (int idx = tid; idx < 9 * NK * 16 * 32; idx += 256) {
+            const int e = idx & 31, j = (idx >> 5) & 15, kk = (idx >> 9) % NK, t = idx / (NK * 512);
+            const int k = kk * 32 + e;
+            Wl[idx] = f32_to_bf16(k < 16 * KQ ? d.w[t + (long long)k * d.wsk + (long long)j * d.wsn] : 0.0f);
+        }
     }
     __syncthreads();
 
