@@ -46,12 +46,13 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_bf16_kernel(const Ige
     const int j0 = blockIdx.y * BN;
 
     for (int r = tid; r < BM; r += NT) {
-        const long long m = m0 + r;
+        const unsigned m = (unsigned)m0 + (unsigned)r;      // (host: M < 2^31; 32-bit divisions)
         RowInfo ri;
-        if (m < M) {
-            const int n = (int)(m / (d.GH * d.GW));
-            const int rem = (int)(m - (long long)n * d.GH * d.GW);
-            const int gi = rem / d.GW, gj = rem - gi * d.GW;
+        if (m < (unsigned)M) {
+            const unsigned ghw = (unsigned)(d.GH * d.GW);
+            const int n = (int)(m / ghw);
+            const unsigned rem = m - (unsigned)n * ghw;
+            const int gi = (int)(rem / (unsigned)d.GW), gj = (int)rem - gi * d.GW;
             ri.src_base = n * d.in_H * d.in_W;
             ri.hs_ws = (gi * d.ss) | ((gj * d.ss) << 16);
             ri.out_pix = (n * d.out_H + gi * d.os + d.goa[grp]) * d.out_W + gj * d.os + d.gob[grp];
@@ -86,9 +87,11 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_bf16_kernel(const Ige
     };
     const __amdgpu_buffer_rsrc_t r_in = make_rsrc(d.in, (unsigned)d.N * d.in_H * d.in_W * d.in_C * 2u);
 
+    int ld_t = tap0, ld_kc = 0, cp_kc = 0;         // (wave-uniform counters)
     auto load_step = [&](int s, Stage &R) __attribute__((always_inline)) {
-        const int t = tap0 + s / kchunks;
-        const int kc = s % kchunks, kc0 = kc * KC;
+        // (steps are loaded in ascending order: the tap and channel chunk of step s are counted, not divided out)
+        const int t = ld_t, kc = ld_kc, kc0 = kc * KC;
+        if (++ld_kc == kchunks) { ld_kc = 0; ++ld_t; }
         const int dh = taps[t * 2 + 0], dw = taps[t * 2 + 1];
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i) {
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_bf16_kernel(const Ige
         const int buf = s & 1;
         if (s + 1 < nsteps) store_step(buf ^ 1, R);
         if (s + 2 < nsteps) load_step(s + 2, R);
-        const int kc0 = (s % kchunks) * KC;
+        const int kc0 = cp_kc * KC;
+        if (++cp_kc == kchunks) cp_kc = 0;
         const unsigned char *Ab = As[buf], *Bb = Bs[buf];
 #pragma unroll
         for (int q = 0; q < KC / 16; ++q) {
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_bf16_kernel(const Ige
     const __amdgpu_buffer_rsrc_t r_ns = make_rsrc(d.epi.nscale, (unsigned)d.N * d.Nout * 4u);
     const bool has_mask = d.epi.mask != nullptr, has_ns = d.epi.nscale != nullptr, has_res = d.epi.res != nullptr;
     const bool relu = d.epi.relu != 0;
+    const bool plain = !has_mask && !has_ns && !has_res;
 #pragma unroll
     for (int a = 0; a < WM; ++a) {
         const RowInfo ri = rows[(wm * WM + a) * 32 + l31];
@@ -182,6 +187,23 @@ __global__ __launch_bounds__(GM *GN * 64, MINW) void igemm_bf16_kernel(const Ige
         const unsigned rbad = (unsigned)(ri.out_pix >> 31) & ERF_OOB;
 #pragma unroll
         for (int b = 0; b < WN; ++b) {
+            if (plain) {        // (wave-uniform) no residual, mask or per-image scale: a third of the general path's instructions
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int cl = (wn * WN + b) * 32 + 8 * g4 + 4 * h;
+                    const unsigned bad = (j0 + cl < d.Nout ? 0u : ERF_OOB) | rbad;
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(&cst[0][cl]);
+                    const f32x4 sh = *reinterpret_cast<const f32x4 *>(&cst[1][cl]);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = acc[a][b][4 * g4 + e] * sc[e] + sh[e];
+                        v[e] = relu ? fmaxf(x, 0.0f) : x;
+                    }
+                    Act<bf16_t>::store4(r_out, (opx * d.out_C + d.out_coff + (unsigned)(j0 + cl)) | bad, v);
+                }
+                continue;
+            }
             f32x4 rres[4], rmask[4], rns[4];
             unsigned cbad[4], cc[4];
 #pragma unroll
