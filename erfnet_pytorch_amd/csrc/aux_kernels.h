@@ -1183,6 +1183,44 @@ __global__ __launch_bounds__(256) void outconv_ce_bwd_kernel(const OutConvCeDesc
         }
     }
     const float scale = d.gy[0] / d.stats[1];
+    // bf16 tensors: the three products on v_mfma_f32_16x16x32_bf16 (16 cycles for 32 contraction slots,
+    // against 32 cycles for 4 on the fp32 instruction).  Lane (i, g) supplies slots 8g .. 8g+7 of both
+    // operands; which contraction element a slot stands for is free as long as both operands agree, so
+    // the slots follow what the lane already holds: channel 4g + j for the logits (j < 4, the upper four
+    // slots are zero), class tile 2S + j/4, position j%4 of the lane's class for the data gradient (the
+    // gradient of the logits as it sits in the accumulators), pixel 4j + g for the weight gradient.  The
+    // weights enter the logits as two bf16 terms (hi + mid: 2^-17 relative, so that exp(logit - lse) agrees
+    // with the forward's log-sum-exp) and the data gradient as one; the gradient of the logits is rounded
+    // to bf16 on its way into the two products, as every activation gradient of the bf16 path is.
+    constexpr bool B16 = sizeof(T) == 2;
+    constexpr int NS = (NT + 1) / 2;
+    auto pack2 = [](float a, float b) __attribute__((always_inline)) {
+        return (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+    };
+    u32x4 wl_hi[NT], wl_mid[NT], wdx[NS];
+    if (B16) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float hi[4], mid[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = bf16_to_f32(f32_to_bf16(wa[t][e]));
+                mid[e] = wa[t][e] - hi[e];
+            }
+            wl_hi[t] = u32x4{pack2(hi[0], hi[1]), pack2(hi[2], hi[3]), 0u, 0u};
+            wl_mid[t] = u32x4{pack2(mid[0], mid[1]), pack2(mid[2], mid[3]), 0u, 0u};
+        }
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+            const bool two = 2 * S + 1 < NT;
+            const int t1 = two ? 2 * S + 1 : 2 * S;
+            wdx[S] = u32x4{pack2(wd[2 * S][0], wd[2 * S][1]), pack2(wd[2 * S][2], wd[2 * S][3]),
+                           two ? pack2(wd[t1][0], wd[t1][1]) : 0u, two ? pack2(wd[t1][2], wd[t1][3]) : 0u};
+        }
+    }
+    auto mfma32 = [](u32x4 a, u32x4 b, f32x4 c) __attribute__((always_inline)) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
 
     f32x4 accw[NT];
     float bsum[NT];
@@ -1200,7 +1238,15 @@ __global__ __launch_bounds__(256) void outconv_ce_bwd_kernel(const OutConvCeDesc
         const unsigned n = mm / HW, rem = mm - n * HW;
         const unsigned y = rem / d.W, x = rem - y * d.W;
         f32x4 xq = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (valid) xq = Act<T>::ld4(d.x, (long long)mm * OC_CIN + 4 * g);
+        u32x4 xb = {0u, 0u, 0u, 0u};            // bf16: the lane's four channels as they sit in memory
+        if (B16) {
+            if (valid) {
+                const u32x2 xr = *reinterpret_cast<const u32x2 *>(reinterpret_cast<const bf16_t *>(d.x) + (long long)mm * OC_CIN + 4 * g);
+                xb[0] = xr[0]; xb[1] = xr[1];
+            }
+            xq = f32x4{__builtin_bit_cast(float, xb[0] << 16), __builtin_bit_cast(float, xb[0] & 0xffff0000u),
+                       __builtin_bit_cast(float, xb[1] << 16), __builtin_bit_cast(float, xb[1] & 0xffff0000u)};
+        } else if (valid) xq = Act<T>::ld4(d.x, (long long)mm * OC_CIN + 4 * g);
         const long long ob = ((long long)n * Ho + 2 * y) * Wo + 2 * x;
         float lse[4];
         long long tg[4];
@@ -1215,10 +1261,17 @@ __global__ __launch_bounds__(256) void outconv_ce_bwd_kernel(const OutConvCeDesc
         f32x4 lg[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) lg[t] = f32x4{bo[t], bo[t], bo[t], bo[t]};
+        if (B16) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+            for (int t = 0; t < NT; ++t) lg[t] = mfma32(wl_mid[t], xb, lg[t]);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) lg[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][kk], xq[kk], lg[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) lg[t] = mfma32(wl_hi[t], xb, lg[t]);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) lg[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][kk], xq[kk], lg[t], 0, 0, 0);
+        }
         // gradient of the logits
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1234,12 +1287,24 @@ __global__ __launch_bounds__(256) void outconv_ce_bwd_kernel(const OutConvCeDesc
         // data gradient (two accumulators: the dependent latency of the instruction exceeds its issue time)
         if (d.dx) {
             f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
+            if (B16) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][0], lg[t][0], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][1], lg[t][1], a1, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][2], lg[t][2], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][3], lg[t][3], a1, 0, 0, 0);
+                for (int S = 0; S < NS; ++S) {
+                    const bool two = 2 * S + 1 < NT;
+                    const int t1 = two ? 2 * S + 1 : 2 * S;
+                    const u32x4 gop = u32x4{pack2(lg[2 * S][0], lg[2 * S][1]), pack2(lg[2 * S][2], lg[2 * S][3]),
+                                            two ? pack2(lg[t1][0], lg[t1][1]) : 0u, two ? pack2(lg[t1][2], lg[t1][3]) : 0u};
+                    if (S & 1) a1 = mfma32(wdx[S], gop, a1);
+                    else a0 = mfma32(wdx[S], gop, a0);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][0], lg[t][0], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][1], lg[t][1], a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][2], lg[t][2], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wd[t][3], lg[t][3], a1, 0, 0, 0);
+                }
             }
             f32x4 v = a0 + a1;
             if (d.mask_dx) {
@@ -1253,14 +1318,31 @@ __global__ __launch_bounds__(256) void outconv_ce_bwd_kernel(const OutConvCeDesc
         for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(&gs[i * PG + 16 * t + 4 * g]) = lg[t];
         *reinterpret_cast<f32x4 *>(&xs[i * 16 + 4 * g]) = xq;
         __builtin_amdgcn_wave_barrier();
+        if (B16) {
+            float xa[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const float xa = xs[(4 * kk + g) * 16 + i];
+            for (int kk = 0; kk < 4; ++kk) xa[kk] = xs[(4 * kk + g) * 16 + i];
+            const u32x4 xop = u32x4{pack2(xa[0], xa[1]), pack2(xa[2], xa[3]), 0u, 0u};     // (exact: x is bf16)
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float gb = gs[(4 * kk + g) * PG + 16 * t + i];
-                bsum[t] += gb;
-                accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, gb, accw[t], 0, 0, 0);
+                float gb[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    gb[kk] = gs[(4 * kk + g) * PG + 16 * t + i];
+                    bsum[t] += gb[kk];
+                }
+                accw[t] = mfma32(xop, u32x4{pack2(gb[0], gb[1]), pack2(gb[2], gb[3]), 0u, 0u}, accw[t]);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float xa = xs[(4 * kk + g) * 16 + i];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float gb = gs[(4 * kk + g) * PG + 16 * t + i];
+                    bsum[t] += gb;
+                    accw[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, gb, accw[t], 0, 0, 0);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
