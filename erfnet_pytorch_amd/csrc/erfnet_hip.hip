@@ -1084,7 +1084,7 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     const long long M = (long long)dd[0].N * dd[0].GH * dd[0].GW;
     if (M == 0) return 0;
     // 128 channels: one 512-thread block per CU owns all 128 x 128 x 3 outputs (X is staged once);
-    // 64 channels: three 256-thread blocks per CU
+    // 64 channels: two 256-thread blocks per CU (slots below)
     const int jtiles = 1;
     // fp32 tensors on the bf16 matrix pipe (split operands): one block per CU; at 64 channels the
     // block's two wave groups write a slab each
@@ -1100,7 +1100,9 @@ int launch_wgrad_line(WgradDesc *dd, int n, float *const *dw, float *const *db, 
     if (no_small < 0) { const char *e = getenv("ERFNET_X3_WGRAD_XR96"); no_small = (e && atoi(e)) ? 1 : 0; }
     const bool x3_small = x3 && NC == 64 && maxdil <= 4 && !no_small;
     const int kgroups = x3 && NC == 64 && !x3_small ? 2 : 1;
-    const int slots = x3_small ? 512 : ((NC == 128 || x3) ? 256 : 768);
+    // (64 channels, bf16 / fp32-MFMA kernels: two blocks per CU — a third one gains the kernel 0.6 us and
+    // costs the slab reduction a third more slabs to read, 5.7 us per run of blocks)
+    const int slots = x3_small ? 512 : ((NC == 128 || x3) ? 256 : 512);
     const size_t slab = (size_t)3 * NC * NC + 3 * NC;
     WgradLineBatch wb;
     memset(&wb, 0, sizeof(wb));
