@@ -328,27 +328,46 @@ __global__ __launch_bounds__(256) void up16_wgrad_kernel(const WgradDesc d)
         cy = rem / W;
         cx = rem - cy * W;
     }
+    // element offsets of the lane's four coarse sources and four fine classes: formed once per image row
+    // (a group later they are 4 coarse / 8 fine pixels further) — formed per group, this arithmetic was
+    // most of the kernel's instructions
+    unsigned soff[4], foff[4];
+    bool row1;
+    auto offsets = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            soff[s] = ((cn * H + cy + (s >> 1)) * W + cx + (s & 1)) * d.in_C + d.in_coff + i + q0 * 16u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            foff[c] = ((cn * 2 * H + 2 * cy + (c >> 1)) * 2 * W + 2 * cx + (c & 1)) * d.g_C + d.g_coff + i;
+        row1 = cy + 1 < H;
+    };
+    offsets();
+    const unsigned sstep = 4u * d.in_C, fstep = 8u * d.g_C;
     auto load_group = [&](unsigned m0, Frag &f) {
         const unsigned p = m0 + g;
         const bool valid = p < wend;
-        const unsigned n = cn, y = cy, x = cx;
-        cx += 4;
-        while (cx >= W) {
-            cx -= W;
-            if (++cy == H) { cy = 0; ++cn; }
-        }
+        const bool col1 = cx + 1 < W;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const unsigned ys = y + (s >> 1), xx = x + (s & 1);
-            const bool ok = valid && ys < H && xx < W;
-            const unsigned off = ((n * H + ys) * W + xx) * d.in_C + d.in_coff + i;
+            const bool ok = valid && ((s >> 1) ? row1 : true) && ((s & 1) ? col1 : true);
 #pragma unroll
-            for (int q = 0; q < KQ; ++q) f.cs[s][q] = Act<T>::load1(r_c, ok ? off + (q0 + q) * 16u : ERF_OOB);
+            for (int q = 0; q < KQ; ++q) f.cs[s][q] = Act<T>::load1(r_c, ok ? soff[s] + q * 16u : ERF_OOB);
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
-            f.fc[c] = Act<T>::load1(r_f, valid ? (px * d.g_C + d.g_coff + i) : ERF_OOB);
+        for (int c = 0; c < 4; ++c) f.fc[c] = Act<T>::load1(r_f, valid ? foff[c] : ERF_OOB);
+        cx += 4;
+        if (cx >= W) {
+            while (cx >= W) {
+                cx -= W;
+                if (++cy == H) { cy = 0; ++cn; }
+            }
+            offsets();
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) soff[s] += sstep;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) foff[c] += fstep;
         }
     };
     auto mfma_group = [&](const Frag &f) {
