@@ -91,6 +91,11 @@ struct IgemmDesc {
     int cfg;           // host side: tile configuration chosen by plan_igemm
     int vec_ok;        // in_C, in_coff, K all multiples of 4 and `in` 16-byte aligned
     int x3_plane;      // igemm_x3_kernel: bf16 elements per plane of the split packed weights
+    // up16_fwd kernels only: the 2x2 max-pool's gradient formed in the epilogue (in place of a residual
+    // tensor written by pool_bwd_kernel): pool_x = the pooled tensor (fine grid, out_C channels),
+    // pool_g = the gradient at the coarse grid, channels [pool_gcoff, pool_gcoff + 16) of pool_gC
+    const void *pool_x, *pool_g;
+    int pool_gC, pool_gcoff;
     double *bn_partial;    // host side, may be null: line_x3_kernel leaves per-block column sums of the output
                            // and of its squares here ([blocks][2 * Nout]: train-mode BatchNorm statistics)
 };

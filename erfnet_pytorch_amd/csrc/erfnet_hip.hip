@@ -1943,18 +1943,13 @@ static int downsampler_backward_impl(int dt, const void *x, long long sn, long l
     }
     if (dx) {
         // dx is NHWC [N,H,W,Cin]: max-pool gradient first, then the conv data gradient on top.
-        PoolBwdDesc p;
-        p.in = x; p.g = g; p.dx = dx; p.N = N; p.H = H; p.W = W; p.C = Cin; p.g_C = Cout; p.g_coff = Cc;
         if (Cin == 3 && (sc != 1 || sw != Cin || sh != (long long)W * Cin || sn != (long long)H * W * Cin))
             return fail("DownsamplerBlock backward: dx for a 3-channel input needs an NHWC input");
-        BY_DT(dt, (pool_bwd_kernel<T><<<grid_for(Mo * Cin, 256, 1u << 30), 256, 0, st>>>(p)));
-        CHECK_LAUNCH("pool_bwd_kernel");
         const ParityTaps pt = parity_taps();
         IgemmDesc d;
         zero_desc(d);
         d.dt = dt;
         d.in = g; d.w = w; d.out = dx;
-        d.epi.res = dx; d.epi.res_C = Cin; d.epi.res_coff = 0;
         if (flags & ERF_BWD_MASK_DX) { d.epi.mask = x; d.epi.mask_C = Cin; }
         d.N = N; d.GH = Ho; d.GW = Wo;
         d.in_H = Ho; d.in_W = Wo; d.in_C = Cout; d.in_coff = 0; d.K = Cc; d.ss = 1;
@@ -1965,6 +1960,22 @@ static int downsampler_backward_impl(int dt, const void *x, long long sn, long l
         }
         for (int t = 0; t < 9; ++t) { d.tdh[t] = pt.dh[t]; d.tdw[t] = pt.dw[t]; d.woff[t] = pt.kh[t] * 3 + pt.kw[t]; }
         d.wsk = Cin * 9; d.wsn = 9;   // W[co][ci][kh][kw]: k = co, j = ci
+        // 16-channel input on the sampler kernel: the pool's gradient is formed in its epilogue (the
+        // lane that holds four channels of a window's four pixels reads the window's gradient);
+        // otherwise pool_bwd_kernel writes it into dx and the convolution adds to it
+        static int no_pool_fuse = -1;
+        if (no_pool_fuse < 0) { const char *e = getenv("ERFNET_NO_POOL_FUSE"); no_pool_fuse = (e && atoi(e)) ? 1 : 0; }
+        const bool x_nhwc16 = sc == 1 && sw == Cin && sh == (long long)W * Cin && sn == (long long)H * W * Cin;
+        if (!no_pool_fuse && Cin == 16 && x_nhwc16 && aligned16(x) && aligned16(g) && Cc % 4 == 0 && Cout % 4 == 0 &&
+            up16_fwd_ok(d)) {
+            d.pool_x = x; d.pool_g = g; d.pool_gC = Cout; d.pool_gcoff = Cc;
+            return launch_up16_fwd(d, st);
+        }
+        PoolBwdDesc p;
+        p.in = x; p.g = g; p.dx = dx; p.N = N; p.H = H; p.W = W; p.C = Cin; p.g_C = Cout; p.g_coff = Cc;
+        BY_DT(dt, (pool_bwd_kernel<T><<<grid_for(Mo * Cin, 256, 1u << 30), 256, 0, st>>>(p)));
+        CHECK_LAUNCH("pool_bwd_kernel");
+        d.epi.res = dx; d.epi.res_C = Cin; d.epi.res_coff = 0;
         if (up16_fwd_ok(d)) {
             if (launch_up16_fwd(d, st)) return 1;
         } else if (launch_igemm(d, ar, st)) return 1;

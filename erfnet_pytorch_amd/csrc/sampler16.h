@@ -26,6 +26,23 @@
 // sit in LDS as [tap][k/16][c][16 k]: a wave's ds_read_b128 covers 1 KiB contiguous (no conflicts).
 // A lane loads channels 16q+4g..+3 of its coarse source pixels; MFMA number m takes element m, so
 // the instruction's k index g stands for channel 16q + 4g + m on both operands.
+// Gradient of a 2x2 max-pool for a lane's four channels: xp[c] = the pooled tensor at the window's
+// four pixels (c = 2*row + column), gp = the gradient at the window; the first largest value takes it
+// (pool_bwd_kernel's order of comparisons).
+__device__ __forceinline__ void s16_pool_grad(const f32x4 (&xp)[4], f32x4 gp, f32x4 (&out)[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int best = 0;
+        float mx = xp[0][r];
+        if (xp[1][r] > mx) { mx = xp[1][r]; best = 1; }
+        if (xp[2][r] > mx) { mx = xp[2][r]; best = 2; }
+        if (xp[3][r] > mx) { mx = xp[3][r]; best = 3; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c][r] = best == c ? gp[r] : 0.0f;
+    }
+}
+
 template <typename T, int KQ>
 __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
 {
@@ -60,6 +77,9 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
     const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * Act<T>::B);
     const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
     const bool has_mask = d.epi.mask != nullptr, relu = d.epi.relu != 0;
+    const bool pooled = d.pool_x != nullptr, px_is_mask = d.pool_x == d.epi.mask;     // (wave-uniform)
+    const __amdgpu_buffer_rsrc_t r_px = make_rsrc(d.pool_x, Pout * d.out_C * Act<T>::B);
+    const __amdgpu_buffer_rsrc_t r_pg = make_rsrc(d.pool_g, M * d.pool_gC * Act<T>::B);
 
     // channel affine of the lane's four output channels 4g..4g+3: v * sc + sh
     f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
@@ -135,6 +155,17 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
                     rres[c] = Act<T>::load4(r_res, tc.valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) : ERF_OOB);
                     rmask[c] = Act<T>::load4(r_mask, tc.valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) : ERF_OOB);
                 }
+                if (pooled) {
+                    f32x4 xp[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned px = (tc.n * 2 * H + 2 * tc.y + (c >> 1)) * 2 * W + 2 * tc.x + (c & 1);
+                        xp[c] = px_is_mask ? rmask[c] : Act<T>::load4(r_px, tc.valid ? (px * d.out_C + 4 * g) : ERF_OOB);
+                    }
+                    const unsigned pos = (tc.n * H + tc.y) * W + tc.x;
+                    const f32x4 gp = Act<T>::load4(r_pg, tc.valid ? (pos * d.pool_gC + d.pool_gcoff + 4 * g) : ERF_OOB);
+                    s16_pool_grad(xp, gp, rres);
+                }
             }
             f32x4 wf[9];
 #pragma unroll
@@ -209,6 +240,9 @@ __global__ __launch_bounds__(256) void up16_fwd_bf16_kernel(const IgemmDesc d)
     const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 2u);
     const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
     const bool has_mask = d.epi.mask != nullptr, relu = d.epi.relu != 0;
+    const bool pooled = d.pool_x != nullptr, px_is_mask = d.pool_x == d.epi.mask;     // (wave-uniform)
+    const __amdgpu_buffer_rsrc_t r_px = make_rsrc(d.pool_x, Pout * d.out_C * 2u);
+    const __amdgpu_buffer_rsrc_t r_pg = make_rsrc(d.pool_g, M * d.pool_gC * 2u);
 
     f32x4 sc = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
     f32x4 sh = buf_load4(r_bias, g * 16u);
@@ -254,6 +288,16 @@ __global__ __launch_bounds__(256) void up16_fwd_bf16_kernel(const IgemmDesc d)
             ooff[c] = valid ? (px * d.out_C + d.out_coff + 4 * g) : ERF_OOB;
             rres[c] = Act<T>::load4(r_res, valid ? (px * d.epi.res_C + d.epi.res_coff + 4 * g) : ERF_OOB);
             rmask[c] = Act<T>::load4(r_mask, valid ? (px * d.epi.mask_C + d.epi.mask_coff + 4 * g) : ERF_OOB);
+        }
+        if (pooled) {
+            f32x4 xp[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned px = (n * 2 * H + 2 * y + (c >> 1)) * 2 * W + 2 * x + (c & 1);
+                xp[c] = px_is_mask ? rmask[c] : Act<T>::load4(r_px, valid ? (px * d.out_C + 4 * g) : ERF_OOB);
+            }
+            const f32x4 gp = Act<T>::load4(r_pg, valid ? (pp * d.pool_gC + d.pool_gcoff + 4 * g) : ERF_OOB);
+            s16_pool_grad(xp, gp, rres);
         }
         f32x4 acc[4];
 #pragma unroll
