@@ -154,9 +154,10 @@ _PROTOS["erf_outconv_forward_bf16"] = (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_in
 
 BWD_GY_PREMASKED, BWD_MASK_DX = 1, 2      # include/erfnet_hip.h
 OPT_PAIR_FUSION, OPT_WGRAD_LINE, OPT_STREAM16, OPT_PAIR16, OPT_LINE2, OPT_SPLIT_BF16, OPT_CONV16_ROWS, OPT_X3_ROLL = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_POOL_FUSE = 9
 
 EXPORTS = tuple(_PROTOS)
-ABI_VERSION = 104                         # ERF_ABI_VERSION of include/erfnet_hip.h
+ABI_VERSION = 105                         # ERF_ABI_VERSION of include/erfnet_hip.h
 
 
 def lib():

@@ -67,6 +67,9 @@ Switch g_sw_conv16_rows("ERFNET_NO_CONV16_ROWS");      // ERF_OPT_CONV16_ROWS
 // the split-bf16 convolutions on the rolling kernel (line_x3r_kernel: every input line split once
 // instead of once per tap); ERFNET_NO_X3R=1 / ERF_OPT_X3_ROLL = 0 keeps line_x3_kernel
 Switch g_sw_x3r("ERFNET_NO_X3R");
+// DownsamplerBlock 16 -> 64 backward: the max-pool's gradient formed in the data-gradient kernel's
+// epilogue; ERFNET_NO_POOL_FUSE=1 / ERF_OPT_POOL_FUSE = 0 keeps pool_bwd_kernel
+Switch g_sw_pool_fuse("ERFNET_NO_POOL_FUSE");
 std::atomic<int> g_line2{1};        // ERF_OPT_LINE2
 // fp32 64 / 128-channel 1-D convolutions on the bf16 matrix pipe, operands split in three bf16 terms
 // (line_x3_kernel, wgrad_line_x3_kernel): fp32 accuracy at 2.7x the fp32 matrix rate.
@@ -1738,6 +1741,7 @@ int erf_set_option(int option, int value)
     if (option == ERF_OPT_LINE2) return g_line2.exchange(value ? 1 : 0);
     if (option == ERF_OPT_CONV16_ROWS) return g_sw_conv16_rows.set(value);
     if (option == ERF_OPT_X3_ROLL) return g_sw_x3r.set(value);
+    if (option == ERF_OPT_POOL_FUSE) return g_sw_pool_fuse.set(value);
     if (option == ERF_OPT_SPLIT_BF16) {
         const int prev = x3_mode();
         g_x3_mode.store(value < 0 ? 0 : (value > 2 ? 2 : value), std::memory_order_relaxed);
@@ -1963,8 +1967,7 @@ static int downsampler_backward_impl(int dt, const void *x, long long sn, long l
         // 16-channel input on the sampler kernel: the pool's gradient is formed in its epilogue (the
         // lane that holds four channels of a window's four pixels reads the window's gradient);
         // otherwise pool_bwd_kernel writes it into dx and the convolution adds to it
-        static int no_pool_fuse = -1;
-        if (no_pool_fuse < 0) { const char *e = getenv("ERFNET_NO_POOL_FUSE"); no_pool_fuse = (e && atoi(e)) ? 1 : 0; }
+        const bool no_pool_fuse = !g_sw_pool_fuse.on();
         const bool x_nhwc16 = sc == 1 && sw == Cin && sh == (long long)W * Cin && sn == (long long)H * W * Cin;
         if (!no_pool_fuse && Cin == 16 && x_nhwc16 && aligned16(x) && aligned16(g) && Cc % 4 == 0 && Cout % 4 == 0 &&
             up16_fwd_ok(d)) {

@@ -50,8 +50,8 @@ typedef struct {
  * mismatch (struct layouts are part of the ABI: revision 101 added erf_bn_t::num_batches_tracked and
  * changed erf_nb1d_block_t's member types, 102 added ERF_OPT_X3_ROLL and the capture rule of
  * erf_cross_entropy_forward_static, 103 added erf_nb1d_block_t::sign_bits / sign_bits_written and
- * erf_nb1d_backward_bits, 104 the erf_batch_* calls). */
-#define ERF_ABI_VERSION 104
+ * erf_nb1d_backward_bits, 104 the erf_batch_* calls, 105 ERF_OPT_POOL_FUSE). */
+#define ERF_ABI_VERSION 105
 int erf_version(void);
 const char *erf_last_error(void);
 /* Number of kernel launches issued through this library by the calling process (tests use it to
@@ -110,6 +110,11 @@ void erf_batch_abort(void);
  * rolling kernel (an input line is split into its bf16 terms once and serves three output lines)
  * instead of once per tap. */
 #define ERF_OPT_X3_ROLL 8
+/* ERF_OPT_POOL_FUSE (default 1; ERFNET_NO_POOL_FUSE=1): erf_downsampler_backward with a 16-channel NHWC
+ * input forms the max-pool's gradient (train/erfnet_blocks.py:29-30: the pooled half of the concatenation)
+ * in the epilogue of the convolution's data-gradient kernel; off = a kernel of its own writes it into dx
+ * first.  Same results bit for bit. */
+#define ERF_OPT_POOL_FUSE 9
 int erf_set_option(int option, int value);
 
 /* Flags of the backward entry points.  Every block ends in a ReLU, so the gradient a block
