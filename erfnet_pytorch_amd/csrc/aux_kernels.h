@@ -16,6 +16,7 @@ struct FirstDownDesc {
     void *out;           // [N][Ho][Wo][Cc+3], storage type T
     Epilogue epi;
     int N, H, W, Cc;
+    unsigned x_elems;    // extent of x covered by its strides when it fits a buffer descriptor (below 2^29), else 0
 };
 
 #define FD_MAX_CC 61
@@ -46,7 +47,26 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
     // columns 2ow-1 .. 2ow+1 of a row come from two aligned pair loads, (2ow-2, 2ow-1) and (2ow, 2ow+1),
     // each of which a wave reads as one contiguous run; otherwise element by element.
     const bool pairs = d.sw == 1 && !((d.sn | d.sc | d.sh) & 1) && !((uintptr_t)d.x & (2 * Act<T>::B - 1));
-    if (pairs) {
+    if (pairs && d.x_elems) {
+        // the eighteen pair loads go out together (buffer loads: a pair outside the image presents an
+        // out-of-range offset and reads zero) — a branch around each load made the wave wait for one
+        // memory round trip after the other
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(d.x, d.x_elems * Act<T>::B);
+        const unsigned sn = (unsigned)d.sn, sc = (unsigned)d.sc, sh = (unsigned)d.sh;
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = 2 * oh - 1 + kh;
+                const bool rok = ih >= 0 && ih < d.H;
+                const unsigned e = (unsigned)n * sn + (unsigned)ci * sc + (unsigned)ih * sh + 2u * (unsigned)ow;
+                const f32x2 lo = Act<T>::load2(rx, (rok && ow > 0) ? e - 2u : ERF_OOB);
+                const f32x2 hi = Act<T>::load2(rx, rok ? e : ERF_OOB);
+                xin[ci * 9 + kh * 3 + 0] = lo[1];
+                xin[ci * 9 + kh * 3 + 1] = hi[0];
+                xin[ci * 9 + kh * 3 + 2] = hi[1];
+            }
+    } else if (pairs) {
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci)
 #pragma unroll

@@ -172,6 +172,10 @@ template <> struct Act<float> {
     static constexpr unsigned B = 4;
     static __device__ __forceinline__ f32x4 load4(__amdgpu_buffer_rsrc_t r, unsigned e) { return buf_load4(r, (e << 2) | (e & ERF_OOB)); }
     static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned e) { return buf_load1(r, (e << 2) | (e & ERF_OOB)); }
+    static __device__ __forceinline__ f32x2 load2(__amdgpu_buffer_rsrc_t r, unsigned e)
+    {
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)((e << 2) | (e & ERF_OOB)), 0, 0));
+    }
     static __device__ __forceinline__ void store4(__amdgpu_buffer_rsrc_t r, unsigned e, f32x4 v) { buf_store4(r, (e << 2) | (e & ERF_OOB), v); }
     static __device__ __forceinline__ void store1(__amdgpu_buffer_rsrc_t r, unsigned e, float v) { buf_store1(r, (e << 2) | (e & ERF_OOB), v); }
     static __device__ __forceinline__ f32x4 ld4(const void *p, long long e) { return *reinterpret_cast<const f32x4 *>((const float *)p + e); }
@@ -190,6 +194,11 @@ template <> struct Act<bf16_t> {
     static __device__ __forceinline__ float load1(__amdgpu_buffer_rsrc_t r, unsigned e)
     {
         return bf16_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, (int)((e << 1) | (e & ERF_OOB)), 0, 0));
+    }
+    static __device__ __forceinline__ f32x2 load2(__amdgpu_buffer_rsrc_t r, unsigned e)
+    {
+        const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(r, (int)((e << 1) | (e & ERF_OOB)), 0, 0);
+        return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
     }
     static __device__ __forceinline__ void store4(__amdgpu_buffer_rsrc_t r, unsigned e, f32x4 v)
     {

@@ -1844,7 +1844,10 @@ static int downsampler_forward_impl(int dt, const void *x, long long sn, long lo
     epi.relu = !two_pass;
     if (Cin == 3) {
         if (Cc > 16) return fail("DownsamplerBlock with 3 input channels supports at most 19 outputs");
-        FirstDownDesc d = {x, sn, sc, sh, sw, w, dst, epi, N, H, W, Cc};
+        // (non-negative strides, an extent a buffer descriptor covers: the kernel's unconditional loads)
+        const long long x_ext = (long long)(N - 1) * sn + 2 * sc + (long long)(H - 1) * sh + (long long)(W - 1) * sw + 1;
+        const bool x_buf = sn >= 0 && sc >= 0 && sh >= 0 && sw >= 0 && x_ext < (1LL << 29);
+        FirstDownDesc d = {x, sn, sc, sh, sw, w, dst, epi, N, H, W, Cc, x_buf ? (unsigned)x_ext : 0u};
         BY_DT(dt, (first_down_fwd_kernel<T><<<(unsigned)((Mo + 255) / 256), 256, 0, st>>>(d)));
         CHECK_LAUNCH("first_down_fwd_kernel");
     } else {
