@@ -111,14 +111,16 @@ class non_bottleneck_1d(nn.Module):
     def _dropout_enabled(self):
         return self.use_dropout and self.dropout.p != 0
 
-    def _gpu_args(self, input):
-        """Keyword arguments of functional.nb1d for this block (draws the dropout mask)."""
+    def _gpu_args(self, input, scale=False):
+        """Keyword arguments of functional.nb1d for this block.  ``scale``: the block's dropout factors
+        when the caller has drawn them (None: dropout does nothing), False: drawn here."""
         mods = self._modules            # direct look-ups: this runs once per block per forward
         convs = [mods[n] for n in self._CONVS]
         mode = _bn_mode(self, self.use_batchnorm)
-        scale = None
-        if self.use_dropout and self.training:
-            scale = _dropout2d_scale(input, mods["dropout"].p, self._dropout_enabled())
+        if scale is False:
+            scale = None
+            if self.use_dropout and self.training:
+                scale = _dropout2d_scale(input, mods["dropout"].p, self._dropout_enabled())
         kw = dict(weights=[c._parameters["weight"] for c in convs], biases=[c._parameters["bias"] for c in convs],
                   dilated=self.dilated, bn_mode=mode, drop_scale=scale)
         if mode:
@@ -150,6 +152,22 @@ def _plain_call(m):
     return not (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks)
 
 
+def _run_dropout_scales(run, x):
+    """Dropout2d factors of a run of blocks: one draw for the whole run when every block drops with the
+    same probability (two launches per run instead of two per block), else block by block (False)."""
+    ps = {m.dropout.p if (m.use_dropout and m.training and m._dropout_enabled()) else 0.0 for m in run}
+    if len(ps) != 1:
+        return [False] * len(run)
+    p = ps.pop()
+    if p == 0:
+        return [None] * len(run)
+    if p >= 1:
+        return [False] * len(run)
+    n, c = x.shape[0], x.shape[1]
+    both = torch.empty(len(run), n, c, dtype=torch.float32, device=x.device).bernoulli_(1.0 - p).div_(1.0 - p)
+    return list(both.unbind(0))
+
+
 def run_layers(layers, x):
     """``for layer in layers: x = layer(x)`` (reference train/net_classification.py:32-36, 42-45).
     On a GPU, runs of consecutive non_bottleneck_1d blocks of one width go to the library as one
@@ -166,7 +184,7 @@ def run_layers(layers, x):
                 j += 1
         if j - i >= 2:
             run = layers[i:j]
-            x = hipf.nb1d_chain(x, [m._gpu_args(x) for m in run])
+            x = hipf.nb1d_chain(x, [m._gpu_args(x, sc) for m, sc in zip(run, _run_dropout_scales(run, x))])
             for m in run:
                 mode = _bn_mode(m, m.use_batchnorm)
                 _bn_tick(m.bn1, mode)

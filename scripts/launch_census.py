@@ -1,5 +1,5 @@
 """Census of the GPU launches of one headline training step (bench.py's step: reducer, flat parameters,
-library Adam): `launch_census.py f32|bf16 [steps]`.  Prints launches per step by kernel name, and for the
+library Adam): `launch_census.py f32|bf16 [steps] [bn]` (bn: eval/erfnet.py's ERFNet(20), BatchNorm + Dropout2d).  Prints launches per step by kernel name, and for the
 kernels torch itself launches (copies, fills, element-wise) the aten op, shapes and the Python frame
 that asked for them."""
 import collections
@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from erfnet_pytorch_amd import net_classification, optim  # noqa: E402
+from erfnet_pytorch_amd import erfnet, net_classification, optim  # noqa: E402
 from erfnet_pytorch_amd.ddp import GradientReducer  # noqa: E402
 from erfnet_pytorch_amd.evaluation_functions import CrossEntropyLoss2d  # noqa: E402
 
@@ -18,20 +18,23 @@ dts = sys.argv[1] if len(sys.argv) > 1 else "f32"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dtype = torch.bfloat16 if dts == "bf16" else torch.float32
 torch.manual_seed(0)
-model = net_classification.Net(softmax_classes=20).to(DEV).train()
+bn = len(sys.argv) > 3 and sys.argv[3] == "bn"
+model = (erfnet.ERFNet(20) if bn else net_classification.Net(softmax_classes=20)).to(DEV).train()
 reducer = GradientReducer(model, bucket_bytes=3_600_000, direct_write=True)
 crit = CrossEntropyLoss2d()
 x = torch.rand(6, 3, 512, 1024, device=DEV).to(dtype)
 lab = torch.randint(-1, 20, (6, 512, 1024), device=DEV)
 reducer.zero_grad()
-crit(model(x)[0], lab).backward()
+out0 = model(x)
+crit(out0 if bn else out0[0], lab).backward()
 reducer.finish()
 opt = optim.Adam(reducer.flatten_parameters(), 1e-4, (0.9, 0.999), eps=1e-4, weight_decay=1e-6)
 
 
 def step():
     reducer.zero_grad()
-    loss = crit(model(x)[0], lab)
+    out = model(x)
+    loss = crit(out if bn else out[0], lab)
     loss.backward()
     reducer.finish()
     opt.step()
@@ -66,7 +69,8 @@ for e in events:
     if e.device_type != torch.autograd.DeviceType.CPU:
         continue
     if e.name not in ("aten::zero_", "aten::fill_", "aten::zeros", "aten::copy_", "aten::cat", "aten::clone",
-                      "aten::_to_copy", "aten::add_", "aten::mul_", "aten::div_", "aten::sum", "aten::mean"):
+                      "aten::_to_copy", "aten::add_", "aten::mul_", "aten::div_", "aten::sum", "aten::mean", "aten::bernoulli_",
+                      "aten::empty", "aten::ones", "aten::full", "aten::ones_like", "aten::zeros_like"):
         continue
     frame = ""
     for f in (e.stack or []):
