@@ -104,15 +104,39 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
         // into 351 vector registers, which left the kernel one wave per SIMD.
         typedef const float __attribute__((address_space(4))) *const_f32;
         const const_f32 wc = (const_f32)(unsigned long long)d.w;
+        // The per-channel constants of the 16 outputs (epi_channel_affine's arithmetic) are formed once,
+        // from vector loads that every lane makes at the same address (an absent vector reads zero): read
+        // by scalar loads inside the channel loop they cost each channel a dependent round trip or two.
+        float scv[16], shv[16];
+        {
+            const BnAffine &bn = d.epi.bn;
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(d.epi.bias, 13u * 4u);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(bn.gamma, bn.on ? 64u : 0u), rbe = make_rsrc(bn.beta, bn.on ? 64u : 0u);
+            const __amdgpu_buffer_rsrc_t rmu = make_rsrc(bn.mean, bn.on ? 64u : 0u), rva = make_rsrc(bn.var, bn.on ? 64u : 0u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b4 = buf_load4(rb, q * 16u), g4 = buf_load4(rg, q * 16u), be4 = buf_load4(rbe, q * 16u);
+                const f32x4 mu4 = buf_load4(rmu, q * 16u), va4 = buf_load4(rva, q * 16u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float sc = 1.0f, sh = b4[e];
+                    if (bn.on) {            // (uniform)
+                        const float inv = bn.var_is_invstd ? va4[e] : rsqrtf(va4[e] + bn.eps);
+                        const float g = (bn.gamma ? g4[e] : 1.0f) * inv;
+                        sh = (sh - mu4[e]) * g + (bn.beta ? be4[e] : 0.0f);
+                        sc = g;
+                    }
+                    scv[q * 4 + e] = sc; shv[q * 4 + e] = sh;
+                }
+            }
+        }
         float v[16];
 #pragma unroll
         for (int co = 0; co < 13; ++co) {
             float acc = 0.0f;
 #pragma unroll
             for (int e = 0; e < 27; ++e) acc = fmaf(xin[e], wc[co * 27 + e], acc);
-            float sc, sh;
-            epi_channel_affine(d.epi, co, sc, sh);
-            v[co] = acc * sc + sh;
+            v[co] = acc * scv[co] + shv[co];
         }
 #pragma unroll
         for (int ci = 0; ci < 3; ++ci) {
@@ -121,11 +145,7 @@ __global__ __launch_bounds__(256) void first_down_fwd_kernel(const FirstDownDesc
             if (b > mx) mx = b;
             if (c > mx) mx = c;
             if (e > mx) mx = e;
-            Epilogue ep = d.epi;
-            ep.bias = nullptr;
-            float sc, sh;
-            epi_channel_affine(ep, 13 + ci, sc, sh);
-            v[13 + ci] = mx * sc + sh;
+            v[13 + ci] = mx * scv[13 + ci] + shv[13 + ci];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
