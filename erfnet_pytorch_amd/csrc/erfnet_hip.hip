@@ -1326,13 +1326,17 @@ int launch_up16_fwd(const IgemmDesc &d, hipStream_t st)
     long long blocks = (M + 63) / 64;             // one 16-position tile per wave at least
     // as many blocks as are resident at once (bf16: three per CU; fp32: two, its waves hold 200+
     // registers): every block pays the weight fill, so further blocks cost more than they hide
-    const long long cap = d.dt ? 768 : 512;
+    // (the bf16 variant that forms the pool gradient holds 164 registers: two blocks per CU)
+    const long long cap = d.dt ? (d.pool_x ? 512 : 768) : 512;
     if (blocks > cap) blocks = cap;
     if (d.dt && d.in_C % 8 == 0 && d.in_coff % 8 == 0 && d.K % 16 == 0 && d.K <= 64) {     // bf16 tensors: bf16 MFMA
         switch (d.K / 16) {
         case 1: up16_fwd_bf16_kernel<1><<<(unsigned)blocks, 256, 0, st>>>(d); break;
         case 2: up16_fwd_bf16_kernel<2><<<(unsigned)blocks, 256, 0, st>>>(d); break;
-        case 3: up16_fwd_bf16_kernel<3><<<(unsigned)blocks, 256, 0, st>>>(d); break;
+        case 3:
+            if (d.pool_x) up16_fwd_bf16_kernel<3, true><<<(unsigned)blocks, 256, 0, st>>>(d);
+            else up16_fwd_bf16_kernel<3><<<(unsigned)blocks, 256, 0, st>>>(d);
+            break;
         default: up16_fwd_bf16_kernel<4><<<(unsigned)blocks, 256, 0, st>>>(d); break;
         }
         CHECK_LAUNCH("up16_fwd_bf16_kernel");
@@ -1341,7 +1345,10 @@ int launch_up16_fwd(const IgemmDesc &d, hipStream_t st)
     switch (d.K / 16) {
     case 1: BY_DT(d.dt, (up16_fwd_kernel<T, 1><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
     case 2: BY_DT(d.dt, (up16_fwd_kernel<T, 2><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
-    case 3: BY_DT(d.dt, (up16_fwd_kernel<T, 3><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
+    case 3:
+        if (d.pool_x) BY_DT(d.dt, (up16_fwd_kernel<T, 3, true><<<(unsigned)blocks, 256, 0, st>>>(d)));
+        else BY_DT(d.dt, (up16_fwd_kernel<T, 3><<<(unsigned)blocks, 256, 0, st>>>(d)));
+        break;
     default: BY_DT(d.dt, (up16_fwd_kernel<T, 4><<<(unsigned)blocks, 256, 0, st>>>(d))); break;
     }
     CHECK_LAUNCH("up16_fwd_kernel");
@@ -1973,7 +1980,7 @@ static int downsampler_backward_impl(int dt, const void *x, long long sn, long l
         const bool no_pool_fuse = !g_sw_pool_fuse.on();
         const bool x_nhwc16 = sc == 1 && sw == Cin && sh == (long long)W * Cin && sn == (long long)H * W * Cin;
         if (!no_pool_fuse && Cin == 16 && x_nhwc16 && aligned16(x) && aligned16(g) && Cc % 4 == 0 && Cout % 4 == 0 &&
-            up16_fwd_ok(d)) {
+            Cc == 48 && up16_fwd_ok(d)) {       // (the pooled kernel variant is built for 48 convolution channels)
             d.pool_x = x; d.pool_g = g; d.pool_gC = Cout; d.pool_gcoff = Cc;
             return launch_up16_fwd(d, st);
         }

@@ -43,7 +43,7 @@ __device__ __forceinline__ void s16_pool_grad(const f32x4 (&xp)[4], f32x4 gp, f3
     }
 }
 
-template <typename T, int KQ>
+template <typename T, int KQ, bool POOL = false>
 __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
 {
     __shared__ __attribute__((aligned(16))) float Wl[9 * KQ * 256];
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
     const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * Act<T>::B);
     const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
     const bool has_mask = d.epi.mask != nullptr, relu = d.epi.relu != 0;
-    const bool pooled = d.pool_x != nullptr, px_is_mask = d.pool_x == d.epi.mask;     // (wave-uniform)
+    constexpr bool pooled = POOL;       // (the host instantiates POOL for a launch with d.pool_x)
+    const bool px_is_mask = d.pool_x == d.epi.mask;     // (wave-uniform)
     const __amdgpu_buffer_rsrc_t r_px = make_rsrc(d.pool_x, Pout * d.out_C * Act<T>::B);
     const __amdgpu_buffer_rsrc_t r_pg = make_rsrc(d.pool_g, M * d.pool_gC * Act<T>::B);
 
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
 // the bf16 data straight from memory as the MFMA operand (16-byte loads, no unpacking): 9 * NK MFMAs
 // of 16 cycles per 16 coarse positions instead of 9 * 4 * KQ of 32.  Weights in LDS as bf16
 // [tap][k / 32][c][32 k] (channels beyond K zero); lane (i, g) holds k = 32 kk + 8 g .. + 7.
-template <int KQ>
+template <int KQ, bool POOL = false>
 __global__ __launch_bounds__(256) void up16_fwd_bf16_kernel(const IgemmDesc d)
 {
     typedef bf16_t T;
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(256) void up16_fwd_bf16_kernel(const IgemmDesc d)
     const __amdgpu_buffer_rsrc_t r_mask = make_rsrc(d.epi.mask, Pout * d.epi.mask_C * 2u);
     const __amdgpu_buffer_rsrc_t r_bias = make_rsrc(d.epi.bias, 64u);
     const bool has_mask = d.epi.mask != nullptr, relu = d.epi.relu != 0;
-    const bool pooled = d.pool_x != nullptr, px_is_mask = d.pool_x == d.epi.mask;     // (wave-uniform)
+    constexpr bool pooled = POOL;       // (the host instantiates POOL for a launch with d.pool_x)
+    const bool px_is_mask = d.pool_x == d.epi.mask;     // (wave-uniform)
     const __amdgpu_buffer_rsrc_t r_px = make_rsrc(d.pool_x, Pout * d.out_C * 2u);
     const __amdgpu_buffer_rsrc_t r_pg = make_rsrc(d.pool_g, M * d.pool_gC * 2u);
 
