@@ -1,4 +1,5 @@
-"""Register / scratch budget of the kernels whose speed hangs on it (CPU test: hipcc cross-compiles gfx950).
+"""Register / scratch budget of the kernels whose speed hangs on it, and a scan of the assembly for a store
+hazard the compiler does not cover (CPU tests: hipcc cross-compiles gfx950).
 
 The line kernels keep their weights in registers and run at exactly the occupancy they were designed for;
 a change that makes the compiler spill (scratch memory) or lose a wave per SIMD costs 10-15 % of a launch
@@ -40,7 +41,8 @@ BUDGET = {
 
 
 @pytest.fixture(scope="module")
-def remarks(tmp_path_factory):
+def listing(tmp_path_factory):
+    """(compiler remarks, path of the gfx950 assembly) of the library's device code, compiled once."""
     if not os.path.exists(HIPCC) or shutil.which("c++filt") is None:
         pytest.skip("hipcc / c++filt not available")
     from erfnet_pytorch_amd import _lib
@@ -49,6 +51,13 @@ def remarks(tmp_path_factory):
            "-Rpass-analysis=kernel-resource-usage", "-o", str(out),
            os.path.join(ROOT, "erfnet_pytorch_amd", "csrc", "erfnet_hip.hip")]
     text = subprocess.run(cmd, capture_output=True, text=True, timeout=900).stderr
+    assert out.exists(), text[-2000:]
+    return text, str(out)
+
+
+@pytest.fixture(scope="module")
+def remarks(listing):
+    text = listing[0]
     recs = re.findall(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)",
                       text, re.S)
     assert recs, "no resource remarks in the compiler's output"
@@ -64,3 +73,14 @@ def test_kernel_keeps_its_occupancy_and_does_not_spill(remarks, kernel):
     for name, (waves, scratch) in hits.items():
         assert waves >= min_waves, f"{name}: {waves} wave(s) per SIMD, designed for {min_waves}"
         assert scratch <= max_scratch, f"{name}: {scratch} bytes of scratch per lane (register spills)"
+
+
+def test_no_wide_store_is_followed_by_a_write_of_its_data(listing):
+    """A 16-byte buffer store whose scalar offset sits in a register fetches its data after it issues and
+    the compiler places no wait state behind it: an instruction right behind the store that overwrites a
+    data register corrupts the last lanes' values (wrong results that depend on timing, which parity tests
+    catch only sometimes).  scripts/scan_store_hazard.py looks for the pattern in the library's assembly."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "scan_store_hazard.py"), listing[1]],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
