@@ -1324,10 +1324,9 @@ int launch_up16_fwd(const IgemmDesc &d, hipStream_t st)
     const long long M = (long long)d.N * d.GH * d.GW;
     if (M == 0) return 0;
     long long blocks = (M + 63) / 64;             // one 16-position tile per wave at least
-    // as many blocks as are resident at once (bf16: three per CU; fp32: two, its waves hold 200+
-    // registers): every block pays the weight fill, so further blocks cost more than they hide
-    // (the bf16 variant that forms the pool gradient holds 164 registers: two blocks per CU)
-    const long long cap = d.dt ? (d.pool_x ? 512 : 768) : 512;
+    // about as many blocks as are resident at once (bf16: three per CU; fp32: two or three — 512 and 768
+    // blocks measure the same): every block pays the weight fill, so further blocks cost more than they hide
+    const long long cap = d.dt ? 768 : 512;
     if (blocks > cap) blocks = cap;
     if (d.dt && d.in_C % 8 == 0 && d.in_coff % 8 == 0 && d.K % 16 == 0 && d.K <= 64) {     // bf16 tensors: bf16 MFMA
         switch (d.K / 16) {

@@ -168,6 +168,9 @@ __global__ __launch_bounds__(256) void up16_fwd_kernel(const IgemmDesc d)
                     s16_pool_grad(xp, gp, rres);
                 }
             }
+            // (nothing moves across a step's boundary: left alone, the compiler reads the weight fragments
+            // of every step ahead of the first MFMA — 236 registers, two waves per SIMD instead of three)
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 wf[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t)
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(256) void up16_fwd_bf16_kernel(const IgemmDesc d)
         for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int kk = 0; kk < NK; ++kk) {
+            __builtin_amdgcn_sched_barrier(0);      // (keeps the next step's weight fragments out of this one's registers)
             bf16x8 wf[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t)

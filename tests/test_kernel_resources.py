@@ -29,11 +29,11 @@ BUDGET = {
     "void conv16_rows_kernel<4, 4, true>(": (3, 0),
     "void conv16_bf16_rows_kernel<8, 2, true>(": (2, 0),
     "void igemm_x3_kernel<2, 1, 2, 2, 2>(": (2, 0),
-    "void up16_fwd_kernel<float, 4, false>(": (2, 0),       # launched with two blocks per CU
-    "void up16_fwd_kernel<float, 3, true>(": (2, 0),
+    "void up16_fwd_kernel<float, 4, false>(": (3, 0),       # (236 registers, two waves, without the barrier between steps)
+    "void up16_fwd_kernel<float, 3, true>(": (3, 0),
     "void up16_fwd_bf16_kernel<4, false>(": (3, 0),         # three blocks per CU
     "void up16_fwd_bf16_kernel<3, false>(": (3, 0),
-    "void up16_fwd_bf16_kernel<3, true>(": (2, 0),          # two (it forms the pool gradient as well)
+    "void up16_fwd_bf16_kernel<3, true>(": (3, 0),
     "void outconv_ce_bwd_kernel<5, unsigned short>(": (2, 0),
     "void first_down_fwd_kernel<float>(": (4, 0),
     "void first_down_fwd_kernel<unsigned short>(": (4, 0),
